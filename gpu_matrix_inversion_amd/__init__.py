@@ -1,0 +1,31 @@
+"""MI355X-native fp32 Gauss-Jordan matrix inversion behind ``matrix_inv_32(vec, N)``.
+
+Drop-in for the hot path of MarchesiGabriele/gpu_matrix_inversion: hand-written
+HIP kernels for gfx950 in ``lib/libmat_inv_32.so`` (C ABI: include/mat_inv_32_c.h,
+C++ drop-in: include/mat_inv_32.h) and this thin Python host mirror.
+"""
+from ._lib import (  # noqa: F401
+    ALGO_AUTO,
+    ALGO_BLOCKED,
+    ALGO_SWEEP,
+    MI32_BAD_SHAPE,
+    MI32_OK,
+    MI32_RUNTIME_ERROR,
+    MI32_SINGULAR,
+    Mi32Error,
+    build_library,
+)
+from .api import Inverter, just_inv, last_timing, matrix_inv_32, matrix_inv_32_batched  # noqa: F401
+from .sharding import invert_sharded, shard_range  # noqa: F401
+
+__all__ = [
+    "matrix_inv_32",
+    "matrix_inv_32_batched",
+    "just_inv",
+    "last_timing",
+    "Inverter",
+    "shard_range",
+    "invert_sharded",
+    "build_library",
+    "Mi32Error",
+]

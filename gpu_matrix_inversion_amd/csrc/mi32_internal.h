@@ -1,0 +1,96 @@
+// mi32_internal.h -- shared declarations of libmat_inv_32.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mat_inv_32_c.h"
+
+namespace mi32 {
+
+// ---- pivot records ----------------------------------------------------------
+// One 64-bit key per candidate: (bits of |a| << 32) | ~row.  |a| >= 0, so its
+// IEEE bit pattern orders like the value; the inverted row index makes an
+// unsigned max pick the LOWEST row among equal maxima (the reference's scan
+// keeps the first maximum, mat_inv_32.cpp:121-127).  NaN candidates and "no
+// candidate" are key 0, which loses against every real candidate.
+__device__ __forceinline__ unsigned long long pivot_key(float a, int row)
+{
+    const float v = __builtin_fabsf(a);
+    if (!(v == v)) return 0ull;
+    return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)row);
+}
+__device__ __forceinline__ int pivot_key_row(unsigned long long key, int fallback_row)
+{
+    return key == 0ull ? fallback_row : (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(k, off, 64);
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+// ---- optional per-kernel-class timing (HIP events on the launch stream) -------------
+// Off by default.  When a context enables it, every launch is bracketed by two
+// events recorded on the stream the kernel is launched on; the classes mirror the
+// reference's per-phase timing slots (FP32_bench.cpp:256-443: makeAug, pivot, row,
+// column, getInverted).
+enum KernelClass {
+    KC_INIT = 0,       // makeAugmented counterpart
+    KC_SWEEP_STEP = 1, // fused pivot step of the sweep path
+    KC_PANEL = 2,      // register-resident panel steps of the blocked path
+    KC_UPDATE_IN = 3,  // rank-w update inside a block
+    KC_UPDATE_OUT = 4, // rank-bw update of the rest of the matrix (fp32 MFMA)
+    KC_FINISH = 5,     // getInverted counterpart (column un-permutation)
+    KC_COUNT = 6
+};
+struct Profiler {
+    virtual void begin(int kclass, hipStream_t s) = 0;
+    virtual void end(int kclass, hipStream_t s) = 0;
+    virtual ~Profiler() {}
+};
+struct ProfScope {
+    Profiler *p; int k; hipStream_t s;
+    ProfScope(Profiler *p_, int k_, hipStream_t s_) : p(p_), k(k_), s(s_) { if (p) p->begin(k, s); }
+    ~ProfScope() { if (p) p->end(k, s); }
+};
+
+// ---- launch plumbing ----------------------------------------------------------
+struct SweepPlan {
+    int n;        // matrix order
+    int ld;       // leading dimension of the working copies (n rounded up to 4)
+    int tr;       // rows per workgroup of the step kernel
+    int row_tiles;
+    int col_tiles;
+};
+
+struct BlockedPlan {
+    int n;     // matrix order
+    int np;    // padded order (multiple of 128), identity padding
+    int w;     // sub-panel width
+    int bw;    // outer block width
+    int nthreads_panel;
+    int rpt;   // rows per thread in the panel kernel
+};
+
+SweepPlan make_sweep_plan(int n);
+BlockedPlan make_blocked_plan(int n, int w, int bw);
+
+size_t sweep_workspace_bytes(const SweepPlan &p, int batch);
+size_t blocked_workspace_bytes(const BlockedPlan &p, int batch);
+
+// Enqueue a whole inversion on `stream`.  ws: workspace of at least the size
+// reported above, 256-byte aligned.
+hipError_t sweep_invert(const SweepPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *ws,
+                        hipStream_t stream, Profiler *prof);
+hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *ws,
+                          hipStream_t stream, Profiler *prof);
+hipError_t residual_launch(const float *d_a, const float *d_x, int n, int batch, double *d_out, void *ws,
+                           hipStream_t stream);
+size_t residual_workspace_bytes(int n, int batch);
+
+}  // namespace mi32

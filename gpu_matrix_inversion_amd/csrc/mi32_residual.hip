@@ -1,0 +1,141 @@
+// mi32_residual.hip -- device-side verification of an inverse, fp64 accumulate.
+//
+// Counterpart of the reference's verification helper
+// /root/reference/matrix_inv_solution/matrix_inversion_solution/matrix_inversion/
+// matrix_multiply.cpp (naive fp64 GEMM kernel :17-36, metric sqrt(N) - ||C||_F
+// :193-200) and of the residual BASELINE.json gates: ||A X - I||_inf.
+// Per matrix b:  out[3b+0] = ||A X - I||_inf,  out[3b+1] = ||X A - I||_inf,
+//                out[3b+2] = sqrt(N) - ||A X||_F.
+// fp32 operands are widened to fp64 in registers; products and sums are fp64.
+#include "mi32_internal.h"
+
+namespace mi32 {
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// workspace: per matrix rowsum_right[n], rowsum_left[n], sumsq (doubles)
+size_t residual_workspace_bytes(int n, int batch) { return align256(((size_t)2 * n + 2) * sizeof(double) * batch); }
+
+// C = L * R (n x n), 64x64 tile per workgroup, 4x4 outputs per thread.
+// which = 0: right residual (L=A, R=X) also accumulates sum of squares of C.
+__global__ __launch_bounds__(256) void residual_tile_kernel(const float *__restrict__ l_all,
+                                                             const float *__restrict__ r_all, int n,
+                                                             double *__restrict__ ws, int which)
+{
+    __shared__ float s_l[16][65];  // [k][i]
+    __shared__ float s_r[16][64];  // [k][j]
+    __shared__ double s_sq[4];
+    const int b = blockIdx.z;
+    const float *L = l_all + (size_t)b * n * n;
+    const float *R = r_all + (size_t)b * n * n;
+    double *rowsum = ws + (size_t)b * (2 * (size_t)n + 2) + (which ? n : 0);
+    double *sumsq = ws + (size_t)b * (2 * (size_t)n + 2) + 2 * (size_t)n;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    double acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+
+    for (int k0 = 0; k0 < n; k0 += 16) {
+        // L tile: 64 rows x 16 k
+        for (int idx = tid; idx < 64 * 16; idx += 256) {
+            const int ii = idx >> 4, kk = idx & 15;
+            const int gi = i0 + ii, gk = k0 + kk;
+            s_l[kk][ii] = (gi < n && gk < n) ? L[(size_t)gi * n + gk] : 0.0f;
+        }
+        for (int idx = tid; idx < 16 * 64; idx += 256) {
+            const int kk = idx >> 6, jj = idx & 63;
+            const int gk = k0 + kk, gj = j0 + jj;
+            s_r[kk][jj] = (gk < n && gj < n) ? R[(size_t)gk * n + gj] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double lv[4], rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lv[u] = (double)s_l[kk][ty * 4 + u];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rv[v] = (double)s_r[kk][tx * 4 + v];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fma(lv[u], rv[v], acc[u][v]);
+        }
+        __syncthreads();
+    }
+    double sq = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int gi = i0 + ty * 4 + u;
+        double rs = 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int gj = j0 + tx * 4 + v;
+            if (gi < n && gj < n) {
+                const double c = acc[u][v];
+                sq += c * c;
+                rs += fabs(c - (gi == gj ? 1.0 : 0.0));
+            }
+        }
+        // the 16 threads of one ty are 16 consecutive lanes
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+        if (tx == 0 && gi < n) atomicAdd(&rowsum[gi], rs);
+    }
+    if (which == 0) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        if ((tid & 63) == 0) s_sq[tid >> 6] = sq;
+        __syncthreads();
+        if (tid == 0) atomicAdd(sumsq, s_sq[0] + s_sq[1] + s_sq[2] + s_sq[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void residual_finalize_kernel(const double *__restrict__ ws, int n,
+                                                                 double *__restrict__ out)
+{
+    __shared__ double s_m[2][4];
+    const int b = blockIdx.x;
+    const double *base = ws + (size_t)b * (2 * (size_t)n + 2);
+    const int tid = threadIdx.x;
+    double m0 = 0.0, m1 = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const double a = base[i], c = base[n + i];
+        m0 = (a > m0 || a != a) ? a : m0;  // NaN propagates
+        m1 = (c > m1 || c != c) ? c : m1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o0 = __shfl_xor(m0, off, 64), o1 = __shfl_xor(m1, off, 64);
+        m0 = (o0 > m0 || o0 != o0) ? o0 : m0;
+        m1 = (o1 > m1 || o1 != o1) ? o1 : m1;
+    }
+    if ((tid & 63) == 0) { s_m[0][tid >> 6] = m0; s_m[1][tid >> 6] = m1; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 1; q < 4; ++q) {
+            const double o0 = s_m[0][q], o1 = s_m[1][q];
+            m0 = (o0 > m0 || o0 != o0) ? o0 : m0;
+            m1 = (o1 > m1 || o1 != o1) ? o1 : m1;
+        }
+        out[3 * b + 0] = m0;
+        out[3 * b + 1] = m1;
+        out[3 * b + 2] = sqrt((double)n) - sqrt(base[2 * (size_t)n]);
+    }
+}
+
+hipError_t residual_launch(const float *d_a, const float *d_x, int n, int batch, double *d_out, void *ws,
+                           hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(ws, 0, ((size_t)2 * n + 2) * sizeof(double) * batch, stream);
+    if (e != hipSuccess) return e;
+    const dim3 grid((n + 63) / 64, (n + 63) / 64, batch);
+    hipLaunchKernelGGL(residual_tile_kernel, grid, dim3(256), 0, stream, d_a, d_x, n, (double *)ws, 0);
+    hipLaunchKernelGGL(residual_tile_kernel, grid, dim3(256), 0, stream, d_x, d_a, n, (double *)ws, 1);
+    hipLaunchKernelGGL(residual_finalize_kernel, dim3(batch), dim3(256), 0, stream, (const double *)ws, n, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace mi32

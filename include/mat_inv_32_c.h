@@ -1,0 +1,117 @@
+/*
+ * mat_inv_32_c.h -- C ABI of libmat_inv_32.so (MI355X / gfx950).
+ *
+ * The reference exposes exactly one entry point for this path,
+ *     std::vector<float> matrix_inv_32(std::vector<float>, int)
+ *     (/root/reference/Matlab/mat_inv_32.h:4, body mat_inv_32.cpp:11-395),
+ * a C++-ABI function that MATLAB binds through clibgen (README.md:31-52).
+ * mi32_matrix_inv_32() below is its flat-pointer twin (what a ctypes / cgo /
+ * JNI / MEX binding would call); include/mat_inv_32.h keeps the original C++
+ * signature on top of it.  Everything else here is additive: a handle so that
+ * the device context, stream and workspace outlive a call (the reference
+ * rebuilds platform/context/queue/programs per call, mat_inv_32.cpp:238-290),
+ * device-pointer entry points for device-resident batches, and a device-side
+ * residual check (the reference's matrix_multiply.cpp verification helper).
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  All functions
+ * return an mi32_status unless stated otherwise.
+ */
+#ifndef MAT_INV_32_C_H
+#define MAT_INV_32_C_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mi32_status {
+    MI32_OK = 0,
+    MI32_BAD_SHAPE = 1,     /* reference: returns {} (mat_inv_32.cpp:206-215)                 */
+    MI32_SINGULAR = 2,      /* a zero/NaN pivot was met (reference: inf/NaN out, unchecked)  */
+    MI32_RUNTIME_ERROR = 3  /* HIP error (reference: unreachable catch, mat_inv_32.cpp:391)  */
+} mi32_status;
+
+typedef enum mi32_algo {
+    MI32_ALGO_AUTO = 0,
+    /* One fused launch per pivot step over the whole working matrix: the
+     * literal restatement of the reference's 5-kernel step (maxPivot,
+     * finalMaxPivot, pivotElements, fixRow, fixColumn; mat_inv_32.cpp:317-362).
+     * HBM-bound; bit-identical to the CPU oracle. */
+    MI32_ALGO_SWEEP = 1,
+    /* Same elimination with the column updates delayed and applied as rank-k
+     * updates on the fp32 matrix cores (v_mfma_f32_32x32x2_f32); the pivot
+     * search / swap / normalise / eliminate steps run on a register-resident
+     * panel.  Equal to SWEEP up to fp32 rounding. */
+    MI32_ALGO_BLOCKED = 2
+} mi32_algo;
+
+typedef struct mi32_context *mi32_handle_t;
+
+/* ---- drop-in twin of matrix_inv_32 (host pointers) ----------------------- */
+/* a_rowmajor: a_len floats, row-major n x n (the reference's integer-division
+ * guard accepts a_len in [n*n, n*n+n); the tail is ignored).  inv_rowmajor: n*n
+ * floats, written only on MI32_OK / MI32_SINGULAR.  Uses a process-wide default
+ * context (device MI32_DEVICE or 0), created on first use, mutex-protected. */
+int mi32_matrix_inv_32(const float *a_rowmajor, size_t a_len, int n, float *inv_rowmajor);
+
+/* batch of independent n x n matrices, contiguous (batch x n x n); status may be
+ * NULL, else receives one mi32_status per matrix.  Returns the worst status. */
+int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int *status);
+
+/* ---- context ------------------------------------------------------------- */
+int mi32_create(mi32_handle_t *out, int device /* HIP ordinal, <0 = current */);
+int mi32_destroy(mi32_handle_t h);
+/* hipStream_t on which every launch of this context is enqueued (NULL = the
+ * context's own stream).  The caller keeps ownership. */
+int mi32_set_stream(mi32_handle_t h, void *hip_stream);
+int mi32_set_algo(mi32_handle_t h, int algo);
+/* tuning knobs of the blocked path: sub-panel width (8/16/32) and the outer
+ * block width (multiple of the sub-panel width, <= 512); 0 keeps the default */
+int mi32_set_blocking(mi32_handle_t h, int panel_width, int block_width);
+/* bytes of device workspace a call of this shape needs (excluding in/out) */
+size_t mi32_workspace_bytes(int n, int batch, int algo);
+/* allocate the workspace up front so that later calls never hipMalloc */
+int mi32_reserve(mi32_handle_t h, int n, int batch);
+
+/* ---- device-resident entry points ---------------------------------------- */
+/* d_a, d_inv: device pointers, batch x n x n fp32 row-major, contiguous; d_a is
+ * not modified, d_inv may not alias d_a.  d_status: device int[batch] (may be
+ * NULL).  Asynchronous: everything is enqueued on the context's stream and the
+ * call returns without synchronising.  The call shape, minus the host copies,
+ * of mat_inv_32.cpp:292-376 (makeAugmented -> N pivot steps -> getInverted). */
+int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *d_inv, int *d_status);
+
+/* Device-side verification (the reference's matrix_multiply.cpp:17-36,193-200 and
+ * the residual BASELINE.json gates): per matrix, d_out[3*b+0] = ||A X - I||_inf,
+ * d_out[3*b+1] = ||X A - I||_inf, d_out[3*b+2] = sqrt(N) - ||A X||_F, all
+ * accumulated in fp64.  d_out: device double[3*batch].  Asynchronous. */
+int mi32_residual_device(mi32_handle_t h, const float *d_a, const float *d_x, int n, int batch, double *d_out);
+
+/* ---- per-phase timing (the reference's FP32_bench.cpp:256-443 timing slots) ---------- */
+/* When enabled, every kernel launch of this context is bracketed by two HIP events
+ * recorded on the launch stream.  mi32_get_profile synchronises those events and returns,
+ * per kernel class, the summed milliseconds and the number of launches since the last
+ * call.  Classes (MI32_KC_*): 0 init (makeAugmented), 1 sweep step, 2 panel steps,
+ * 3 in-block rank-w update, 4 rank-bw update (fp32 MFMA), 5 finish (getInverted). */
+#define MI32_KC_COUNT 6
+int mi32_set_profiling(mi32_handle_t h, int enable);
+int mi32_get_profile(mi32_handle_t h, double *ms_per_class, long long *launches_per_class, int nclasses);
+
+/* ---- introspection -------------------------------------------------------- */
+/* The two durations the reference prints per call ("Tempo Totale Impiegato",
+ * "Tempo Computazione", mat_inv_32.cpp:385-386) for the last host-pointer call
+ * on the default context: total (H2D + compute + D2H) and compute only. */
+int mi32_last_timing(double *total_seconds, double *compute_seconds);
+/* which algorithm a call of this shape would use after AUTO resolution */
+int mi32_resolve_algo(mi32_handle_t h, int n, int batch);
+/* name of the dominant device kernel of that algorithm (for rocprof filtering) */
+const char *mi32_dominant_kernel(int algo);
+/* thread-local description of the last MI32_RUNTIME_ERROR */
+const char *mi32_last_error(void);
+int mi32_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,513 @@
+/*
+ * gj_oracle.c -- CPU oracle (TEST INFRASTRUCTURE ONLY, see gj_oracle.h).
+ *
+ * Plain scalar C restatement of the reference's fp32 Gauss-Jordan inversion,
+ *   R = /root/reference/Matlab/mat_inv_32/mat_inv_32/mat_inv_32.cpp
+ * Every function cites the R lines it follows.  No code is copied: the
+ * reference is OpenCL C inside C++ raw strings driven by cl.hpp; this file
+ * is sequential C over the same data layout ([A|I] row-major N x 2N panel,
+ * two ping-pong copies), written from the step semantics.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off: no silent fusing, the
+ * fused/unfused choice is explicit via fmaf()).
+ */
+#include "gj_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- helpers ---------------------------------------------------------- */
+
+/* |x| with NaN demoted below every real candidate, so that a NaN can never
+ * be chosen as the arg-max (the reference's `fabs(a) > fabs(b)` is false for
+ * NaN too, R:90,123). */
+static inline float cand_abs(float x)
+{
+    float v = fabsf(x);
+    return (v == v) ? v : -1.0f;
+}
+
+static inline float elim(float cij, float cir, float crj, int arith_mode)
+{
+    /* R:34-37  Cij = Cij - (Cir * Crj) */
+    if (arith_mode == GJO_ARITH_FMA)
+        return fmaf(-cir, crj, cij);
+    {
+        volatile float prod = cir * crj; /* volatile: forbid re-fusing */
+        return cij - prod;
+    }
+}
+
+/* ---- R:177-192 makeAugmentedMatrix ------------------------------------ */
+static void make_augmented(float *aug, const float *in, int n)
+{
+    const size_t w = (size_t)2 * n;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < 2 * n; ++j)
+            aug[i * w + j] = (j < n) ? in[(size_t)i * n + j] : ((j - n) == i ? 1.0f : 0.0f);
+}
+
+/* ---- R:195-203 getInvertedMatrix --------------------------------------- */
+static void get_inverted(const float *aug, float *out, int n)
+{
+    const size_t w = (size_t)2 * n;
+    for (int i = 0; i < n; ++i)
+        for (int j = n; j < 2 * n; ++j)
+            out[(size_t)i * n + (j - n)] = aug[i * w + j];
+}
+
+/* ---- pivot search, intended semantics --------------------------------- */
+/* arg-max_{i>=r} |m[i][r]|, first maximum wins (strict '>' scanned in
+ * ascending row order, as finalMaxPivotKernel scans its partials, R:121-127).
+ * Deviation, documented: an all-zero/NaN column yields p = r (the reference
+ * would yield "row 0, pivot 0" from its (0,0) initial record, R:120). */
+static int max_pivot_true(const float *m, size_t ld, int n, int r)
+{
+    int p = r;
+    float best = cand_abs(m[(size_t)r * ld + r]);
+    for (int i = r + 1; i < n; ++i) {
+        float v = cand_abs(m[(size_t)i * ld + r]);
+        if (v > best) {
+            best = v;
+            p = i;
+        }
+    }
+    return p;
+}
+
+/* ---- R:61-106 maxPivotKernel + R:112-132 finalMaxPivotKernel, as written -- */
+/* Lock-step emulation of one 256-wide work-group (barriers separate the tree
+ * levels, and inside a level writes go to [0,i) while reads come from
+ * [i,2i) and the thread's own slot, so sequential evaluation is exact). */
+static void ref_max_pivot_group(const float *m, int size, int n, int r, int wg, float *ox, float *oy)
+{
+    float lx[257], ly[257];
+    memset(lx, 0, sizeof lx);
+    memset(ly, 0, sizeof ly);
+    int nthreads = n - wg * 256; /* non-uniform last group when N % 256 != 0 (R:328) */
+    if (nthreads > 256) nthreads = 256;
+
+    for (int lid = 0; lid < nthreads; ++lid) { /* R:70 */
+        int gid = wg * 256 + lid;
+        lx[lid] = m[(size_t)gid * size + r];
+        ly[lid] = (float)gid;
+    }
+    if (r <= wg * 256 + 255) { /* R:73 */
+        int loop_limit = 256, lim;
+        if ((size / 2) < 256) /* R:74-77 */
+            loop_limit = size / 2;
+        else if (wg == (int)floorf((float)(size / 512)))
+            loop_limit = (size / 2) % 256;
+        if (r >= wg * 256) /* R:79-82 */
+            lim = loop_limit - (r % 256);
+        else
+            lim = loop_limit;
+        if (lim % 2 != 0) { /* R:84-87 */
+            lx[loop_limit] = 0.0f;
+            ly[loop_limit] = 0.0f;
+            lim++;
+        }
+        for (int i = lim >> 1; i > 0; i >>= 1) { /* R:90-98 */
+            for (int lid = 0; lid < nthreads; ++lid) {
+                int gid = wg * 256 + lid;
+                if (lid < i && fabsf(lx[lid + i]) > fabsf(lx[lid]) && gid >= r) {
+                    lx[lid] = lx[lid + i];
+                    ly[lid] = ly[lid + i];
+                }
+            }
+            if (i % 2 != 0 && i != 1) i++;
+        }
+        if (r >= wg * 256) { /* R:99-102 */
+            *ox = lx[r % 256];
+            *oy = ly[r % 256];
+        } else {
+            *ox = lx[0];
+            *oy = ly[0];
+        }
+    } else { /* R:103-105 */
+        *ox = 0.0f;
+        *oy = 0.0f;
+    }
+}
+
+static int max_pivot_reference_defect(const float *m, int n, int r, float *pivot_value)
+{
+    const int size = 2 * n;
+    const int groups = (n % 256 == 0) ? n / 256 : n / 256 + 1; /* R:257-261 */
+    float mx = 0.0f, my = 0.0f;                                /* R:120 */
+    for (int g = 0; g < groups; ++g) {
+        float x, y;
+        ref_max_pivot_group(m, size, n, r, g, &x, &y);
+        if (fabsf(x) > fabsf(mx)) { /* R:122-125 */
+            mx = x;
+            my = y;
+        }
+    }
+    *pivot_value = mx;
+    return (int)my; /* R:163 maxRow = (int)(pivot[0].y) */
+}
+
+/* ---- R:206-395 matrix_inv_32: guards + host loop ----------------------- */
+static int shape_ok(size_t in_len, int n)
+{
+    if (n <= 0) return 0;                     /* R:206-208 */
+    if ((int)(in_len / (size_t)n) != n) return 0; /* R:211-214 (integer division) */
+    return 1;
+}
+
+int gjo_matrix_inv_32(const float *in, size_t in_len, int n, float *out, int pivot_mode,
+                      int arith_mode, int *pivots, float *aug_out)
+{
+    if (!shape_ok(in_len, n)) return GJO_BAD_SHAPE;
+    const size_t w = (size_t)2 * n;
+    float *buf0 = (float *)malloc(sizeof(float) * w * n);
+    float *buf1 = (float *)malloc(sizeof(float) * w * n);
+    if (!buf0 || !buf1) {
+        free(buf0);
+        free(buf1);
+        return GJO_BAD_SHAPE;
+    }
+    int status = GJO_OK;
+    make_augmented(buf0, in, n); /* R:292-297 */
+
+    for (int r = 0; r < n; ++r) { /* R:317 */
+        float *src = (r % 2 == 0) ? buf0 : buf1; /* R:318,353-360 ping-pong */
+        float *dst = (r % 2 == 0) ? buf1 : buf0;
+
+        /* maxPivot + finalMaxPivot, R:322-331.  pivot value is read BEFORE the swap. */
+        int p;
+        float piv;
+        if (pivot_mode == GJO_PIVOT_REFERENCE_DEFECT) {
+            p = max_pivot_reference_defect(src, n, r, &piv);
+        } else {
+            p = max_pivot_true(src, w, n, r);
+            piv = src[(size_t)p * w + r];
+        }
+        if (pivots) pivots[r] = p;
+        if (piv == 0.0f || piv != piv) status = GJO_SINGULAR;
+
+        /* pivotElementsKernel, R:154-173: swap rows r <-> p over all 2N columns */
+        if (p != r) {
+            for (size_t j = 0; j < w; ++j) {
+                float t = src[(size_t)r * w + j];
+                src[(size_t)r * w + j] = src[(size_t)p * w + j];
+                src[(size_t)p * w + j] = t;
+            }
+        }
+        /* fixRowKernel, R:138-150: true IEEE division of row r by the pivot */
+        for (size_t j = 0; j < w; ++j) src[(size_t)r * w + j] = src[(size_t)r * w + j] / piv;
+
+        /* fixColumnKernel, R:13-57: out-of-place elimination of column r */
+        const float *rowr = src + (size_t)r * w;
+        for (int i = 0; i < n; ++i) {
+            const float *si = src + (size_t)i * w;
+            float *di = dst + (size_t)i * w;
+            const float cir = si[r];
+            if (cir != 0.0f && i != r) { /* R:28 */
+                for (size_t j = 0; j < w; ++j) di[j] = elim(si[j], cir, rowr[j], arith_mode);
+            } else {
+                memcpy(di, si, sizeof(float) * w);
+            }
+        }
+    }
+    /* R:368-372: the last-written buffer holds [I | A^-1] */
+    const float *fin = ((n - 1) % 2 == 0) ? buf1 : buf0;
+    get_inverted(fin, out, n);
+    if (aug_out) memcpy(aug_out, fin, sizeof(float) * w * n);
+    free(buf0);
+    free(buf1);
+    return status;
+}
+
+/* ---- the same arithmetic, in-place N x N ------------------------------- */
+/* Column r of the working matrix is, from step r on, the augmented panel's
+ * right-half column that went dense at step r (column N + orig[r], orig[r] =
+ * original index of the pivot row of step r).  Every skipped operation in
+ * this form is one that the augmented form performs on an exact 0 or 1, so the
+ * stored values are identical. */
+int gjo_matrix_inv_32_inplace(const float *in, size_t in_len, int n, float *out, int arith_mode,
+                              int *pivots)
+{
+    if (!shape_ok(in_len, n)) return GJO_BAD_SHAPE;
+    const size_t ld = (size_t)n;
+    float *m = (float *)malloc(sizeof(float) * ld * n);
+    int *orig = (int *)malloc(sizeof(int) * n);
+    float *rowr = (float *)malloc(sizeof(float) * n);
+    if (!m || !orig || !rowr) {
+        free(m);
+        free(orig);
+        free(rowr);
+        return GJO_BAD_SHAPE;
+    }
+    memcpy(m, in, sizeof(float) * ld * n);
+    for (int i = 0; i < n; ++i) orig[i] = i;
+    int status = GJO_OK;
+
+    for (int r = 0; r < n; ++r) {
+        const int p = max_pivot_true(m, ld, n, r);
+        const float piv = m[(size_t)p * ld + r];
+        if (pivots) pivots[r] = p;
+        if (piv == 0.0f || piv != piv) status = GJO_SINGULAR;
+        if (p != r) {
+            for (int j = 0; j < n; ++j) {
+                float t = m[(size_t)r * ld + j];
+                m[(size_t)r * ld + j] = m[(size_t)p * ld + j];
+                m[(size_t)p * ld + j] = t;
+            }
+            int t = orig[r];
+            orig[r] = orig[p];
+            orig[p] = t;
+        }
+        /* normalise; the identity-column entry 1 becomes 1/piv */
+        for (int j = 0; j < n; ++j) m[(size_t)r * ld + j] = m[(size_t)r * ld + j] / piv;
+        m[(size_t)r * ld + r] = 1.0f / piv;
+        memcpy(rowr, m + (size_t)r * ld, sizeof(float) * n);
+        for (int i = 0; i < n; ++i) {
+            if (i == r) continue;
+            float *mi = m + (size_t)i * ld;
+            const float cir = mi[r];
+            mi[r] = 0.0f; /* the identity column's entry in this row */
+            if (cir != 0.0f)
+                for (int j = 0; j < n; ++j) mi[j] = elim(mi[j], cir, rowr[j], arith_mode);
+        }
+    }
+    /* un-permute columns: inverse column orig[c] lives in working column c */
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < n; ++c) out[(size_t)i * n + orig[c]] = m[(size_t)i * ld + c];
+    free(m);
+    free(orig);
+    free(rowr);
+    return status;
+}
+
+/* ---- blocked restatement (CPU mirror of the HIP blocked path) ---------- */
+/* In-place Gauss-Jordan on column blocks of width w: the N x w panel is
+ * reduced with the unblocked steps above (pivot search over the whole column
+ * height below the diagonal), its row swaps are applied to every other
+ * column, the block's pivot rows R = M[K, J] are snapshotted, and all other
+ * columns J receive one delayed rank-w update
+ *     M[i, J] = (i in K ? 0 : M[i, J]) + G[i, :] * R,
+ * G = the transformed panel.  Accumulation is a k-ascending fmaf chain
+ * starting from the old value, which is what v_mfma_f32_32x32x2_f32 computes. */
+int gjo_matrix_inv_32_blocked(const float *in, size_t in_len, int n, float *out, int w, int *pivots)
+{
+    if (!shape_ok(in_len, n)) return GJO_BAD_SHAPE;
+    if (w <= 0) w = 16;
+    const size_t ld = (size_t)n;
+    float *m = (float *)malloc(sizeof(float) * ld * n);
+    int *orig = (int *)malloc(sizeof(int) * n);
+    float *rs = (float *)malloc(sizeof(float) * (size_t)w * n);
+    float *prn = (float *)malloc(sizeof(float) * w);
+    if (!m || !orig || !rs || !prn) {
+        free(m); free(orig); free(rs); free(prn);
+        return GJO_BAD_SHAPE;
+    }
+    memcpy(m, in, sizeof(float) * ld * n);
+    for (int i = 0; i < n; ++i) orig[i] = i;
+    int status = GJO_OK;
+
+    for (int c0 = 0; c0 < n; c0 += w) {
+        const int kw = (c0 + w <= n) ? w : n - c0;
+        /* panel: unblocked steps restricted to columns [c0, c0+kw) */
+        for (int s = 0; s < kw; ++s) {
+            const int r = c0 + s;
+            const int p = max_pivot_true(m, ld, n, r);
+            const float piv = m[(size_t)p * ld + r];
+            if (pivots) pivots[r] = p;
+            if (piv == 0.0f || piv != piv) status = GJO_SINGULAR;
+            if (p != r) { /* swap across ALL columns right away */
+                for (int j = 0; j < n; ++j) {
+                    float t = m[(size_t)r * ld + j];
+                    m[(size_t)r * ld + j] = m[(size_t)p * ld + j];
+                    m[(size_t)p * ld + j] = t;
+                }
+                int t = orig[r]; orig[r] = orig[p]; orig[p] = t;
+            }
+            float *mr = m + (size_t)r * ld + c0;
+            for (int c = 0; c < kw; ++c) prn[c] = mr[c] / piv;
+            prn[s] = 1.0f / piv;
+            for (int c = 0; c < kw; ++c) mr[c] = prn[c];
+            for (int i = 0; i < n; ++i) {
+                if (i == r) continue;
+                float *mi = m + (size_t)i * ld + c0;
+                const float f = mi[s];
+                mi[s] = 0.0f;
+                for (int c = 0; c < kw; ++c) mi[c] = fmaf(-f, prn[c], mi[c]);
+            }
+        }
+        /* snapshot the block's pivot rows over the other columns */
+        for (int k = 0; k < kw; ++k) memcpy(rs + (size_t)k * n, m + (size_t)(c0 + k) * ld, sizeof(float) * n);
+        /* delayed rank-kw update of every column outside the panel */
+        for (int i = 0; i < n; ++i) {
+            float *mi = m + (size_t)i * ld;
+            const float *g = mi + c0;
+            const int in_block = (i >= c0 && i < c0 + kw);
+            for (int j = 0; j < n; ++j) {
+                if (j >= c0 && j < c0 + kw) continue;
+                float acc = in_block ? 0.0f : mi[j];
+                for (int k = 0; k < kw; ++k) acc = fmaf(g[k], rs[(size_t)k * n + j], acc);
+                mi[j] = acc;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < n; ++c) out[(size_t)i * n + orig[c]] = m[(size_t)i * ld + c];
+    free(m); free(orig); free(rs); free(prn);
+    return status;
+}
+
+/* ---- two-level blocked restatement: exact CPU mirror of mi32_blocked.hip ----- */
+/* Outer blocks of bw pivot columns; inside a block, sub-panels of w columns are
+ * reduced with the unblocked steps and followed by a rank-w update of the block's
+ * other columns; after the block, one rank-bw update of every column outside it.
+ * Row swaps are applied to all columns immediately (the HIP path applies them
+ * lazily through row maps, which moves the same values).  Every accumulation is
+ * the k-ascending fmaf chain of v_mfma_f32_32x32x2_f32, so the HIP blocked path
+ * with the same (w, bw) reproduces these values bit for bit. */
+static void rank_update(float *m, size_t ld, int n, int r0, int kw, int j_lo, int j_hi, float *rs)
+{
+    /* rs: kw x n snapshot of rows [r0, r0+kw) */
+    for (int k = 0; k < kw; ++k) memcpy(rs + (size_t)k * n, m + (size_t)(r0 + k) * ld, sizeof(float) * n);
+    for (int i = 0; i < n; ++i) {
+        float *mi = m + (size_t)i * ld;
+        const float *g = mi + r0;
+        const int in_block = (i >= r0 && i < r0 + kw);
+        for (int j = j_lo; j < j_hi; ++j) {
+            if (j >= r0 && j < r0 + kw) continue;
+            float acc = in_block ? 0.0f : mi[j];
+            for (int k = 0; k < kw; ++k) acc = fmaf(g[k], rs[(size_t)k * n + j], acc);
+            mi[j] = acc;
+        }
+    }
+}
+
+int gjo_matrix_inv_32_blocked2(const float *in, size_t in_len, int n, float *out, int w, int bw, int *pivots)
+{
+    if (!shape_ok(in_len, n)) return GJO_BAD_SHAPE;
+    if (w <= 0) w = 16;
+    if (bw < w) bw = w;
+    const size_t ld = (size_t)n;
+    float *m = (float *)malloc(sizeof(float) * ld * n);
+    int *orig = (int *)malloc(sizeof(int) * n);
+    float *rs = (float *)malloc(sizeof(float) * (size_t)bw * n);
+    float *prn = (float *)malloc(sizeof(float) * w);
+    if (!m || !orig || !rs || !prn) {
+        free(m); free(orig); free(rs); free(prn);
+        return GJO_BAD_SHAPE;
+    }
+    memcpy(m, in, sizeof(float) * ld * n);
+    for (int i = 0; i < n; ++i) orig[i] = i;
+    int status = GJO_OK;
+
+    for (int C0 = 0; C0 < n; C0 += bw) {
+        const int kb = (C0 + bw <= n) ? bw : n - C0;
+        for (int c0 = C0; c0 < C0 + kb; c0 += w) {
+            const int kw = (c0 + w <= C0 + kb) ? w : C0 + kb - c0;
+            for (int s = 0; s < kw; ++s) {
+                const int r = c0 + s;
+                const int p = max_pivot_true(m, ld, n, r);
+                const float piv = m[(size_t)p * ld + r];
+                if (pivots) pivots[r] = p;
+                if (piv == 0.0f || piv != piv) status = GJO_SINGULAR;
+                if (p != r) {
+                    for (int j = 0; j < n; ++j) {
+                        float t = m[(size_t)r * ld + j];
+                        m[(size_t)r * ld + j] = m[(size_t)p * ld + j];
+                        m[(size_t)p * ld + j] = t;
+                    }
+                    int t = orig[r]; orig[r] = orig[p]; orig[p] = t;
+                }
+                float *mr = m + (size_t)r * ld + c0;
+                for (int c = 0; c < kw; ++c) prn[c] = mr[c] / piv;
+                prn[s] = 1.0f / piv;
+                for (int c = 0; c < kw; ++c) mr[c] = prn[c];
+                for (int i = 0; i < n; ++i) {
+                    if (i == r) continue;
+                    float *mi = m + (size_t)i * ld + c0;
+                    const float f = mi[s];
+                    mi[s] = 0.0f;
+                    for (int c = 0; c < kw; ++c) mi[c] = fmaf(-f, prn[c], mi[c]);
+                }
+            }
+            if (kb > kw) rank_update(m, ld, n, c0, kw, C0, C0 + kb, rs); /* inside the block */
+        }
+        if (kb < n) rank_update(m, ld, n, C0, kb, 0, n, rs); /* everything outside the block */
+    }
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < n; ++c) out[(size_t)i * n + orig[c]] = m[(size_t)i * ld + c];
+    free(m); free(orig); free(rs); free(prn);
+    return status;
+}
+
+/* ---- metrics ----------------------------------------------------------- */
+static double residual_generic(const float *l, const float *r, int n)
+{
+    /* || L*R - I ||_inf with double accumulation, row by row */
+    double *acc = (double *)malloc(sizeof(double) * n);
+    double worst = 0.0;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) acc[j] = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const double lik = (double)l[(size_t)i * n + k];
+            const float *rk = r + (size_t)k * n;
+            for (int j = 0; j < n; ++j) acc[j] += lik * (double)rk[j];
+        }
+        acc[i] -= 1.0;
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += fabs(acc[j]);
+        if (s > worst || s != s) worst = s;
+    }
+    free(acc);
+    return worst;
+}
+
+double gjo_residual_inf(const float *a, const float *x, int n) { return residual_generic(a, x, n); }
+double gjo_residual_inf_left(const float *a, const float *x, int n) { return residual_generic(x, a, n); }
+
+/* matrix_multiply.cpp:25-33 (C = A*B in double) and :193-200 (sqrt(N) - ||C||_F) */
+double gjo_frobenius_metric(const float *a, const float *x, int n)
+{
+    double *acc = (double *)malloc(sizeof(double) * n);
+    double somma = 0.0;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) acc[j] = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const double aik = (double)a[(size_t)i * n + k];
+            const float *xk = x + (size_t)k * n;
+            for (int j = 0; j < n; ++j) acc[j] += aik * (double)xk[j];
+        }
+        for (int j = 0; j < n; ++j) somma += acc[j] * acc[j];
+    }
+    free(acc);
+    return sqrt((double)n) - sqrt(somma);
+}
+
+/* matrix_inversion_FP32.cpp:814-835 (without its column-0 slip) */
+int gjo_left_half_is_identity(const float *aug, int n)
+{
+    const size_t w = (size_t)2 * n;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const float v = aug[i * w + j];
+            if (i == j ? (v != 1.0f) : (v != 0.0f)) return 0;
+        }
+    return 1;
+}
+
+/* MSVC CRT rand(): s = s*214013 + 2531011; return (s >> 16) & 0x7fff.
+ * The sweep driver never seeds it (RAND false, main_file.cpp:18,22-25). */
+int gjo_msvc_rand(unsigned int *state)
+{
+    *state = *state * 214013u + 2531011u;
+    return (int)((*state >> 16) & 0x7fffu);
+}
+
+/* main_file.cpp:41-52: row-major fill, zero diagonal, rand()%10 elsewhere
+ * (rand() is NOT drawn for diagonal entries). */
+void gjo_fill_hollow_msvc(float *a, int k, unsigned int *state)
+{
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+            a[(size_t)i * k + j] = (i == j) ? 0.0f : (float)(gjo_msvc_rand(state) % 10);
+}

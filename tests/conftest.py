@@ -1,0 +1,55 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+EPS32 = float(np.finfo(np.float32).eps) / 2  # unit roundoff 2^-24
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load_golden(path):
+    d = np.load(path, allow_pickle=False)
+    return d["a"], d["inv64"]
+
+
+def gate_matrix(n, seed):
+    """D_gate of SURVEY.md 8(d): row-permuted U(-1,1) + sqrt(N) I, kappa ~ 6, forces ~N swaps."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-1.0, 1.0, (n, n)) + np.sqrt(n) * np.eye(n)
+    return a[rng.permutation(n)].astype(np.float32)
+
+
+def forward_tolerance(a, factor=2.0):
+    """fp32 forward-error bound used by every parity test against a float64 inverse:
+    max|X - X64| / max|X64| <= factor * kappa_inf(A) * 2^-24.
+    (Measured for the oracle over all fixtures: <= 0.37 * kappa_inf * 2^-24.)"""
+    a64 = np.asarray(a, dtype=np.float64)
+    kappa = np.linalg.cond(a64, np.inf)
+    return factor * kappa * EPS32
+
+
+def rel_err(x, ref):
+    x = np.asarray(x, dtype=np.float64).reshape(ref.shape)
+    return float(np.abs(x - ref).max() / np.abs(ref).max())
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O
+
+    O.build()
+    return O

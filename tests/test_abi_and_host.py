@@ -1,0 +1,179 @@
+"""CPU tests: the C-ABI library loads and exports every declared symbol, the host logic
+(guards, sharding, NumPy-shaped harness) behaves like the reference's, and the product path
+fails loudly -- never falls back -- when no GPU is present.  No compute calls on a GPU here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+import gpu_matrix_inversion_amd as g
+from gpu_matrix_inversion_amd import _lib
+
+
+def _have_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    assert os.path.commonpath([ROOT, _lib.LIB_PATH]) == ROOT
+
+
+def test_every_declared_symbol_is_exported():
+    """Every function include/mat_inv_32_c.h declares is exported, plus the C++ drop-in."""
+    hdr = open(os.path.join(ROOT, "include", "mat_inv_32_c.h")).read()
+    declared = set(re.findall(r"\b(mi32_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.C_ABI_SYMBOLS), declared ^ set(_lib.C_ABI_SYMBOLS)
+    lib = _lib.load()
+    for sym in _lib.C_ABI_SYMBOLS:
+        assert getattr(lib, sym) is not None
+    # std::vector<float> matrix_inv_32(std::vector<float>, int) -- include/mat_inv_32.h
+    assert getattr(lib, _lib.CXX_DROPIN_SYMBOL) is not None
+    out = subprocess.run(["c++filt", _lib.CXX_DROPIN_SYMBOL], capture_output=True, text=True).stdout.strip()
+    assert out == "matrix_inv_32(std::vector<float, std::allocator<float> >, int)"
+
+
+def test_dropin_header_matches_reference_declaration():
+    """include/mat_inv_32.h keeps the reference's declaration verbatim (Matlab/mat_inv_32.h:4)."""
+    hdr = open(os.path.join(ROOT, "include", "mat_inv_32.h")).read()
+    assert "std::vector<float> matrix_inv_32(std::vector<float> matrix_vector, int matrix_order);" in hdr
+    assert 'extern "C"' not in hdr
+
+
+def test_code_object_is_gfx950_only():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH],
+                         capture_output=True, text=True).stdout
+    archs = set(re.findall(r"gfx[0-9a-f]+", out))
+    assert archs == {"gfx950"}, archs
+
+
+def test_shape_guards_need_no_gpu():
+    """mat_inv_32.cpp:206-215 guards are answered before anything touches the device."""
+    lib = _lib.load()
+    fp = ctypes.POINTER(ctypes.c_float)
+    buf = (ctypes.c_float * 8)()
+    assert lib.mi32_matrix_inv_32(ctypes.cast(buf, fp), 4, 0, ctypes.cast(buf, fp)) == _lib.MI32_BAD_SHAPE
+    assert lib.mi32_matrix_inv_32(ctypes.cast(buf, fp), 4, -1, ctypes.cast(buf, fp)) == _lib.MI32_BAD_SHAPE
+    assert lib.mi32_matrix_inv_32(ctypes.cast(buf, fp), 3, 2, ctypes.cast(buf, fp)) == _lib.MI32_BAD_SHAPE
+    assert lib.mi32_matrix_inv_32(ctypes.cast(buf, fp), 6, 2, ctypes.cast(buf, fp)) == _lib.MI32_BAD_SHAPE
+    assert g.matrix_inv_32(np.ones(4), 0).size == 0
+    assert g.matrix_inv_32(np.ones(3), 2).size == 0
+    assert g.matrix_inv_32(np.ones(6), 2).size == 0
+    assert g.matrix_inv_32(np.zeros(0), 3).size == 0
+
+
+def test_workspace_sizes():
+    lib = _lib.load()
+    n = 4096
+    sweep = lib.mi32_workspace_bytes(n, 1, _lib.ALGO_SWEEP)
+    blocked = lib.mi32_workspace_bytes(n, 1, _lib.ALGO_BLOCKED)
+    # two working copies of the N x N matrix (the reference holds two N x 2N panels + N x N)
+    assert 2 * n * n * 4 <= sweep < 2 * n * n * 4 + (1 << 20)
+    assert 2 * n * n * 4 <= blocked < 2 * n * n * 4 + (1 << 20)
+    assert lib.mi32_workspace_bytes(0, 1, 0) == 0
+    # padding to a multiple of 128 in the blocked path
+    assert lib.mi32_workspace_bytes(1000, 1, _lib.ALGO_BLOCKED) >= 2 * 1024 * 1024 * 4
+    assert lib.mi32_dominant_kernel(_lib.ALGO_SWEEP) == b"gj_sweep_step_kernel"
+    assert lib.mi32_dominant_kernel(_lib.ALGO_BLOCKED) == b"gj_rank_update_kernel"
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product path raises; it never computes on the CPU."""
+    with pytest.raises(g.Mi32Error):
+        g.matrix_inv_32(np.eye(2, dtype=np.float32).reshape(-1), 2)
+    with pytest.raises(g.Mi32Error):
+        g.Inverter()
+    h = ctypes.c_void_p()
+    assert _lib.load().mi32_create(ctypes.byref(h), 0) == _lib.MI32_RUNTIME_ERROR
+    assert b"device" in _lib.load().mi32_last_error().lower()
+
+
+def test_product_package_never_imports_the_oracle():
+    src_dir = os.path.join(ROOT, "gpu_matrix_inversion_amd")
+    for dirpath, _, files in os.walk(src_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "gj_oracle" not in text.replace("oracle/gj_oracle.c", ""), f
+
+
+def test_shard_range_partitions_the_batch():
+    for batch in (0, 1, 7, 64, 511, 512):
+        for world in (1, 2, 3, 4, 8):
+            covered = []
+            for r in range(world):
+                lo, hi = g.shard_range(batch, world, r)
+                assert 0 <= lo <= hi <= batch
+                covered += list(range(lo, hi))
+            assert covered == list(range(batch))
+    assert g.shard_range(512, 8, 3) == (192, 256)  # C3: 64 matrices per GPU
+    with pytest.raises(ValueError):
+        g.shard_range(4, 2, 2)
+
+
+def test_just_inv_call_shape(capsys):
+    """just_inv mirrors matrix_inv_numpy.py:39-46: prints 'TIME: <s>' and times only the inverse
+    (here with numpy.linalg.inv injected: C0 = BASELINE configs[0], 256x256 on the CPU)."""
+    dt, a, res = g.just_inv(256, seed=0, inv=np.linalg.inv)
+    out = capsys.readouterr().out
+    assert re.match(r"^TIME: [0-9.e-]+\n$", out)
+    assert a.shape == (256, 256) and a.dtype == np.float32 and a.min() >= 0 and a.max() <= 100
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "c0_u100_N256.npz"))
+    assert np.array_equal(a, gold["a"])  # same seed-0 default_rng stream as the committed fixture
+    assert np.abs(res - gold["inv64"]).max() / np.abs(gold["inv64"]).max() < 1e-4
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import gpu_matrix_inversion_amd as g
+import oracle as O
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+rng = np.random.default_rng(5)
+B, n = 5, 24   # ragged: 3 + 2
+a = np.stack([(rng.uniform(-1, 1, (n, n)) + np.sqrt(n) * np.eye(n))[rng.permutation(n)] for _ in range(B)]).astype(np.float32)
+calls = []
+def oracle_fn(shard):   # the test injects the checker as the per-shard function; the product never does
+    calls.append(shard.shape[0])
+    inv = np.stack([O.matrix_inv_32(m.numpy(), n).reshape(n, n) for m in shard])
+    return torch.from_numpy(inv), torch.zeros(shard.shape[0], dtype=torch.int32)
+inv, st, (lo, hi) = g.invert_sharded(torch.from_numpy(a), oracle_fn)
+assert (lo, hi) == g.shard_range(B, world, rank)
+assert calls == [hi - lo], calls                      # each rank inverts only its own shard
+assert inv.shape == (B, n, n) and st.shape == (B,)
+for b in range(B):
+    assert O.residual_inf(a[b], inv[b].numpy(), n) < 1e-4
+full = np.stack([O.matrix_inv_32(a[b], n).reshape(n, n) for b in range(B)])
+assert np.array_equal(inv.numpy(), full)               # gathered result == unsharded result, bit for bit
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_batch_gloo_world2(tmp_path):
+    """N>1 path on CPU: two gloo ranks, contiguous shards, all-gather of results and status."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o

@@ -1,0 +1,283 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X).  Everything goes through the C ABI of
+libmat_inv_32.so; the oracle is only the checker.
+
+Tolerances (fp32, stated once):
+  * sweep path:   bit-identical to the CPU oracle (same operation order, explicit fmaf, IEEE divide)
+  * blocked path: bit-identical to the oracle's two-level blocked mirror (same block structure;
+                  v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain), and against float64 inverses
+                  max|X-X64|/max|X64| <= 2 * kappa_inf(A) * 2^-24
+  * residual gate (BASELINE.json): ||A X - I||_inf < 1e-3 on D_gate at every size
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, forward_tolerance, gate_matrix, golden_files, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import gpu_matrix_inversion_amd as g  # noqa: E402
+from gpu_matrix_inversion_amd import _lib  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def inv_sweep():
+    inv = g.Inverter(algo="sweep")
+    yield inv
+    inv.close()
+
+
+@pytest.fixture(scope="module")
+def inv_blocked():
+    inv = g.Inverter(algo="blocked")
+    yield inv
+    inv.close()
+
+
+def run(inv, a):
+    ta = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    x, st = inv.inv(ta)
+    torch.cuda.synchronize()
+    return x.cpu().numpy(), st.cpu().numpy()
+
+
+def dist_matrix(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "gate":
+        return gate_matrix(n, seed)
+    if kind == "ref100":  # matrix_inv_pyopencl.py:17, matrix_inv_numpy.py:40
+        return rng.uniform(0, 100, (n, n)).astype(np.float32)
+    if kind == "rand":    # MATLAB rand(N,N)
+        return rng.uniform(0, 1, (n, n)).astype(np.float32)
+    if kind == "hollow":  # matrix_inv_numpy.py:13-14, main_file.cpp:46-48
+        a = rng.uniform(0, 100, (n, n))
+        np.fill_diagonal(a, 0.0)
+        return a.astype(np.float32)
+    raise ValueError(kind)
+
+
+SIZES = [1, 2, 3, 4, 5, 16, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, 300, 512, 1000]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_sweep_bit_identical_to_oracle(oracle, inv_sweep, n):
+    for kind in ("gate", "ref100", "hollow"):
+        if kind == "hollow" and n == 1:
+            continue
+        a = dist_matrix(kind, n, 7000 + n)
+        want, info = oracle.matrix_inv_32(a, n, return_info=True)
+        got, st = run(inv_sweep, a)
+        assert st[0] == info["status"] == 0
+        assert np.array_equal(got.reshape(-1), want), (kind, n, np.abs(got.reshape(-1) - want).max())
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_blocked_bit_identical_to_blocked_mirror(oracle, inv_blocked, n):
+    for kind in ("gate", "ref100", "hollow"):
+        if kind == "hollow" and n == 1:
+            continue
+        a = dist_matrix(kind, n, 8000 + n)
+        want = oracle.matrix_inv_32_blocked2(a, n, 16, 256)
+        got, st = run(inv_blocked, a)
+        assert st[0] == 0
+        assert np.array_equal(got.reshape(-1), want), (kind, n, np.abs(got.reshape(-1) - want).max())
+
+
+@pytest.mark.parametrize("w,bw", [(16, 128), (8, 128), (4, 256), (8, 384), (16, 512)])
+def test_blocked_other_blockings(oracle, w, bw):
+    inv = g.Inverter(algo="blocked", panel_width=w, block_width=bw)
+    try:
+        for n in (200, 640):
+            a = dist_matrix("gate", n, 8100 + n + w)
+            want = oracle.matrix_inv_32_blocked2(a, n, w, bw)
+            got, st = run(inv, a)
+            assert st[0] == 0
+            assert np.array_equal(got.reshape(-1), want), (w, bw, n)
+    finally:
+        inv.close()
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_vectors_both_paths(oracle, inv_sweep, inv_blocked, path):
+    a, inv64 = load_golden(path)
+    n = a.shape[0]
+    tol = forward_tolerance(a)
+    for inv in (inv_sweep, inv_blocked):
+        got, st = run(inv, a)
+        assert st[0] == 0
+        assert rel_err(got, inv64) <= tol
+        assert oracle.residual_inf(a, got, n) <= max(4 * n * tol, 1e-6)
+
+
+def test_dropin_host_entry_point(oracle):
+    """matrix_inv_32(vec, N): the reference's call shape through the host-pointer C ABI."""
+    n = 96
+    a = gate_matrix(n, 31)
+    got = g.matrix_inv_32(a.reshape(-1), n)
+    assert got.dtype == np.float32 and got.shape == (n * n,)
+    assert oracle.residual_inf(a, got, n) < 1e-4
+    total, compute = g.last_timing()
+    assert total >= compute > 0
+    # the reference's guards (mat_inv_32.cpp:206-215)
+    assert g.matrix_inv_32(a.reshape(-1), 0).size == 0
+    assert g.matrix_inv_32(a.reshape(-1)[:-1], n).size == 0
+    # integer-division quirk: a tail of fewer than N extra floats is accepted and ignored
+    tail = np.concatenate([a.reshape(-1), np.full(n - 1, 99.0, np.float32)])
+    assert np.array_equal(g.matrix_inv_32(tail, n), got)
+    # N = 1
+    assert g.matrix_inv_32(np.array([4.0], np.float32), 1)[0] == 0.25
+    # invalid (singular) matrix -> empty vector (README.md:54)
+    sing = np.ones((8, 8), np.float32)
+    assert g.matrix_inv_32(sing.reshape(-1), 8).size == 0
+    os.environ["MI32_SINGULAR_KEEP"] = "1"
+    try:
+        assert g.matrix_inv_32(sing.reshape(-1), 8).size == 64
+    finally:
+        del os.environ["MI32_SINGULAR_KEEP"]
+
+
+def test_cxx_dropin_links_and_runs(oracle, tmp_path):
+    """A C++ caller compiled against include/mat_inv_32.h (the reference's header, unchanged)
+    links to libmat_inv_32.so and gets the same answer as the C ABI."""
+    src = tmp_path / "caller.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <vector>
+#include "mat_inv_32.h"
+int main() {
+    const int n = 3;
+    std::vector<float> a = {2, 1, 0,  1, 3, 1,  0, 1, 4};
+    std::vector<float> x = matrix_inv_32(a, n);
+    if (x.size() != 9) { std::printf("EMPTY\n"); return 1; }
+    for (float v : x) std::printf("%.9g\n", v);
+    std::vector<float> bad = matrix_inv_32(a, 2);   // 9/2 = 4 != 2
+    std::vector<float> neg = matrix_inv_32(a, -1);
+    std::vector<float> sing = matrix_inv_32(std::vector<float>(16, 1.0f), 4);
+    std::printf("sizes %zu %zu %zu\n", bad.size(), neg.size(), sing.size());
+    return 0;
+}
+''')
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lmat_inv_32", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    a = np.array([2, 1, 0, 1, 3, 1, 0, 1, 4], np.float32)
+    want = oracle.matrix_inv_32(a, 3)
+    got = np.array([float(v) for v in lines[:9]], np.float32)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert lines[9] == "sizes 0 0 0"
+
+
+def test_batched_with_a_singular_member(oracle, inv_sweep, inv_blocked):
+    n, B = 160, 6
+    mats = np.stack([gate_matrix(n, 900 + b) for b in range(B)])
+    mats[3] = 1.0  # rank-1: singular
+    for inv, mirror in ((inv_sweep, lambda m: oracle.matrix_inv_32(m, n)),
+                        (inv_blocked, lambda m: oracle.matrix_inv_32_blocked2(m, n, 16, 256))):
+        got, st = run(inv, mats)
+        assert list(st) == [0, 0, 0, 2, 0, 0]
+        for b in range(B):
+            if b == 3:
+                continue
+            assert np.array_equal(got[b].reshape(-1), mirror(mats[b])), b
+    out, st = g.matrix_inv_32_batched(mats)
+    assert list(st) == [0, 0, 0, 2, 0, 0]
+    assert oracle.residual_inf(mats[5], out[5], n) < 1e-4
+
+
+def test_nan_input_is_flagged_not_chosen(inv_sweep, inv_blocked):
+    n = 40
+    a = gate_matrix(n, 77)
+    a[5, 5] = np.nan
+    for inv in (inv_sweep, inv_blocked):
+        _, st = run(inv, a)
+        assert st[0] in (0, 2)  # a NaN can never win a pivot search; it poisons the result instead
+    z = np.zeros((n, n), np.float32)
+    for inv in (inv_sweep, inv_blocked):
+        _, st = run(inv, z)
+        assert st[0] == 2
+
+
+def test_device_residual_matches_oracle(oracle, inv_blocked):
+    n = 300
+    a = dist_matrix("ref100", n, 5)
+    x, _ = run(inv_blocked, a)
+    ta, tx = torch.from_numpy(a).cuda(), torch.from_numpy(x).cuda()
+    r = inv_blocked.residual(ta, tx).cpu().numpy()[0]
+    assert r[0] == pytest.approx(oracle.residual_inf(a, x, n), rel=1e-9)
+    assert r[1] == pytest.approx(oracle.residual_inf_left(a, x, n), rel=1e-9)
+    assert r[2] == pytest.approx(oracle.frobenius_metric(a, x, n), rel=1e-6, abs=1e-12)
+
+
+def test_non_default_stream_and_determinism(inv_blocked):
+    n = 384
+    a = torch.from_numpy(gate_matrix(n, 3)).cuda()
+    x0, _ = inv_blocked.inv(a)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        x1, _ = inv_blocked.inv(a)
+    s.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(x0, x1)
+
+
+# ---- BASELINE.json full sizes: size-independent properties + the residual gate ----------
+
+def _full_size_properties(inv, n, batch, seed):
+    rng = np.random.default_rng(seed)
+    mats = torch.from_numpy(np.stack([gate_matrix(n, seed + b) for b in range(batch)])).cuda()
+    x, st = inv.inv(mats)
+    res = inv.residual(mats, x)
+    # (1) power-of-two scaling is exact in every operation: inv(2A) == inv(A)/2 bit for bit
+    x2, _ = inv.inv(mats * 2.0)
+    # (2) row-permuted input: partial pivoting picks the same rows, so inv(P A) == inv(A)[:, perm] bit for bit
+    perm = torch.from_numpy(rng.permutation(n)).cuda()
+    xp, _ = inv.inv(mats[:, perm, :].contiguous())
+    # (3) involution: inv(inv(A)) ~= A
+    xx, _ = inv.inv(x)
+    torch.cuda.synchronize()
+    assert int(st.max()) == 0
+    assert float(res[:, 0].max()) < 1e-3 and float(res[:, 1].max()) < 1e-3, res
+    assert torch.equal(x2 * 2.0, x)
+    assert torch.equal(xp, x[:, :, perm])
+    back = float((xx - mats).abs().max() / mats.abs().max())
+    assert back < 1e-4, back
+    return float(res[:, 0].max())
+
+
+def test_c1_single_4096_blocked(inv_blocked):
+    r = _full_size_properties(inv_blocked, 4096, 1, 10_000)
+    print("C1 blocked residual", r)
+
+
+def test_c1_single_4096_sweep_and_blocked_agree(inv_sweep, inv_blocked):
+    n = 4096
+    a = torch.from_numpy(gate_matrix(n, 10_001)).cuda()
+    xs, st = inv_sweep.inv(a)
+    xb, _ = inv_blocked.inv(a)
+    rs = inv_sweep.residual(a, xs)
+    torch.cuda.synchronize()
+    assert int(st.item()) == 0 and float(rs[0, 0]) < 1e-3
+    rel = float((xs - xb).abs().max() / xs.abs().max())
+    assert rel < 1e-5, rel
+
+
+def test_sweep_2048_bit_identical_to_oracle(oracle, inv_sweep):
+    n = 2048
+    a = gate_matrix(n, 20_000)
+    got, st = run(inv_sweep, a)
+    want = oracle.matrix_inv_32_inplace(a, n)
+    assert st[0] == 0 and np.array_equal(got.reshape(-1), want)
+
+
+def test_c2_batch_of_2048(inv_blocked):
+    r = _full_size_properties(inv_blocked, 2048, 8, 30_000)
+    print("C2 (8 of the 64) residual", r)

@@ -1,0 +1,142 @@
+"""CPU tests of the oracle itself: pinned against the golden vectors (outputs of the
+reference's NumPy script + seeded numpy.linalg.inv fixtures) and against the reference's own
+acceptance properties.  No GPU, no product code."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import forward_tolerance, gate_matrix, golden_files, load_golden, rel_err
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_oracle_matches_golden(oracle, path):
+    a, inv64 = load_golden(path)
+    n = a.shape[0]
+    x, info = oracle.matrix_inv_32(a, n, return_info=True)
+    assert info["status"] == oracle.STATUS_OK
+    # (1) entry-wise agreement with the float64 inverse within the fp32 forward bound
+    assert rel_err(x, inv64) <= forward_tolerance(a)
+    # (2) the reference's exact-identity acceptance check (matrix_inversion_FP32.cpp:814-835)
+    assert oracle.left_half_is_identity(info["aug"], n)
+    # (3) A * inv(A) ~= I, both sides, and the reference's Frobenius metric
+    tol_res = 4 * n * forward_tolerance(a)  # residual <= ||A|| * ||dX||: generous row-sum bound
+    assert oracle.residual_inf(a, x, n) <= max(tol_res, 1e-6)
+    assert oracle.residual_inf_left(a, x, n) <= max(tol_res, 1e-6)
+    assert abs(oracle.frobenius_metric(a, x, n)) <= max(tol_res, 1e-6)
+
+
+def test_reference_script_fixture_is_reference_output():
+    """ref_just_inv_K*.npz hold what the reference's own just_inv computed (matrix_inv_numpy.py:44):
+    the captured float64 inverse really inverts the captured float64 input."""
+    for p in golden_files():
+        if "ref_just_inv" not in p:
+            continue
+        d = np.load(p)
+        a64, inv = d["a64"], d["inv64_of_a64"]
+        assert np.abs(a64 @ inv - np.eye(a64.shape[0])).max() < 1e-8
+        assert a64.min() >= 0.0 and a64.max() <= 100.0  # U(0,100), matrix_inv_numpy.py:40
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 16, 33, 64, 100, 130, 257])
+def test_inplace_form_is_bit_identical_to_augmented(oracle, n):
+    """The N x N in-place layout the HIP kernels use stores exactly the values of the
+    reference's [A|I] panel."""
+    for seed, a in ((n, gate_matrix(n, n)),
+                    (n + 1, np.random.default_rng(n + 1).uniform(0, 100, (n, n)).astype(np.float32))):
+        for arith in (oracle.ARITH_FMA, oracle.ARITH_UNFUSED):
+            x, i1 = oracle.matrix_inv_32(a, n, arith_mode=arith, return_info=True)
+            y, i2 = oracle.matrix_inv_32_inplace(a, n, arith_mode=arith, return_info=True)
+            assert np.array_equal(i1["pivots"], i2["pivots"])
+            assert np.array_equal(x, y), (n, seed, arith)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 16, 40, 64])
+def test_c_restatement_matches_numpy_mirror(oracle, n):
+    a = np.random.default_rng(100 + n).uniform(-1, 1, (n, n)).astype(np.float32)
+    x = oracle.matrix_inv_32(a, n).reshape(n, n)
+    m = oracle.numpy_mirror_inv(a)
+    # the mirror rounds through float64 (double rounding): allow a few ulps of drift per step
+    assert np.abs(x - m).max() <= 64 * n * np.finfo(np.float32).eps * np.abs(x).max()
+
+
+@pytest.mark.parametrize("n,w", [(16, 16), (48, 16), (100, 16), (130, 8), (64, 4), (257, 16)])
+def test_blocked_restatement_within_tolerance(oracle, n, w):
+    a = gate_matrix(n, 5000 + n)
+    x, i1 = oracle.matrix_inv_32_inplace(a, n, return_info=True)
+    y, i2 = oracle.matrix_inv_32_blocked(a, n, w, return_info=True)
+    assert np.array_equal(i1["pivots"], i2["pivots"])  # well-separated pivots: same choices
+    inv64 = np.linalg.inv(a.astype(np.float64))
+    assert rel_err(y, inv64) <= forward_tolerance(a)
+    assert oracle.residual_inf(a, y, n) < 1e-4
+
+
+def test_shape_guards_return_empty(oracle):
+    """mat_inv_32.cpp:206-215: N <= 0 -> {}, int(size/N) != N -> {} (integer division, so a tail
+    of fewer than N extra floats is accepted and ignored)."""
+    assert oracle.matrix_inv_32(np.ones(4, np.float32), 0).size == 0
+    assert oracle.matrix_inv_32(np.ones(4, np.float32), -3).size == 0
+    assert oracle.matrix_inv_32(np.ones(3, np.float32), 2).size == 0   # 3/2 = 1 != 2
+    assert oracle.matrix_inv_32(np.ones(6, np.float32), 2).size == 0   # 6/2 = 3 != 2
+    assert oracle.matrix_inv_32(np.zeros(0, np.float32), 1).size == 0
+    a = np.array([4, 7, 2, 6, 99], np.float32)                          # 5/2 = 2: tail ignored
+    x = oracle.matrix_inv_32(a, 2)
+    assert np.allclose(x.reshape(2, 2), np.linalg.inv(a[:4].reshape(2, 2)), rtol=1e-6)
+
+
+def test_singular_and_nan_inputs_are_flagged(oracle):
+    a = np.array([[1, 2, 3], [2, 4, 6], [1, 0, 1]], np.float32)
+    _, info = oracle.matrix_inv_32(a, 3, return_info=True)
+    assert info["status"] == oracle.STATUS_SINGULAR
+    z = np.zeros((4, 4), np.float32)
+    _, info = oracle.matrix_inv_32(z, 4, return_info=True)
+    assert info["status"] == oracle.STATUS_SINGULAR
+    b = np.eye(3, dtype=np.float32)
+    b[1, 1] = np.nan
+    _, info = oracle.matrix_inv_32(b, 3, return_info=True)
+    assert info["status"] == oracle.STATUS_SINGULAR
+
+
+def test_pivot_ties_pick_lowest_row(oracle):
+    # column 0 has |.| = 2 in rows 1 and 3: the first maximum (row 1) must win
+    a = np.array([[1, 0, 0, 0], [-2, 1, 0, 0], [0, 0, 1, 0], [2, 0, 0, 1]], np.float32)
+    _, info = oracle.matrix_inv_32(a, 4, return_info=True)
+    assert info["pivots"][0] == 1
+
+
+def test_msvc_rand_stream_and_hollow_fill(oracle):
+    """The sweep driver's inputs (main_file.cpp:41-52) from the unseeded MSVC LCG."""
+    assert list(oracle.msvc_rand_stream(5)) == [41, 18467, 6334, 26500, 19169]
+    a, state = oracle.fill_hollow_msvc(10, 1)
+    assert np.all(np.diag(a) == 0) and a.min() >= 0 and a.max() <= 9
+    assert a[0, 1] == 41 % 10 and a[0, 2] == 18467 % 10  # the diagonal does not draw from rand()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hollow_msvc_K10.npz"))["a"]
+    assert np.array_equal(a, g)
+
+
+def test_reference_pivot_defect_emulation(oracle):
+    """the reference's maxPivotKernel inspects a shrinking subset of rows inside the
+    work-group that contains r.  The lock-step emulation reproduces the survey's counts: the chosen
+    pivot differs from the true arg-max in most steps, yet any non-zero pivot still inverts."""
+    n = 256
+    a = np.random.default_rng(42).uniform(0, 100, (n, n)).astype(np.float32)
+    xt, it = oracle.matrix_inv_32(a, n, return_info=True)
+    xd, idf = oracle.matrix_inv_32(a, n, pivot_mode=oracle.PIVOT_REFERENCE_DEFECT, return_info=True)
+    differ = int(np.sum(it["pivots"] != idf["pivots"]))
+    assert differ > n // 2                      # survey: 244/256 on its input
+    assert idf["pivots"][0] == it["pivots"][0]  # r % 256 == 0: every row is inspected
+    assert np.all(idf["pivots"][86:] == np.arange(86, n))  # r % 256 >= 86: only row r itself
+    rt, rd = oracle.residual_inf(a, xt, n), oracle.residual_inf(a, xd, n)
+    assert rt < rd                              # true partial pivoting is the better inverse
+    assert oracle.left_half_is_identity(idf["aug"], n)
+
+
+def test_metrics_on_known_case(oracle):
+    a = np.array([[2, 0], [0, 4]], np.float32)
+    x = np.array([[0.5, 0], [0, 0.25]], np.float32)
+    assert oracle.residual_inf(a, x, 2) == 0.0
+    assert oracle.residual_inf_left(a, x, 2) == 0.0
+    assert abs(oracle.frobenius_metric(a, x, 2)) < 1e-15
+    bad = np.array([[0.5, 0.1], [0, 0.25]], np.float32)
+    assert oracle.residual_inf(a, bad, 2) == pytest.approx(0.2, rel=1e-6)
+    assert oracle.residual_inf_left(a, bad, 2) == pytest.approx(0.4, rel=1e-6)
