@@ -37,13 +37,16 @@ namespace mi32 {
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 static constexpr int kPanelThreads = 512;
-static constexpr int kPanelWaves = kPanelThreads / 64;
 
 BlockedPlan make_blocked_plan(int n, int w, int bw)
 {
     BlockedPlan p;
     p.n = n;
     p.np = (n + 127) & ~127;
+    // Row stride: np + 64 floats.  A power-of-two stride would put the same column chunk of every
+    // row on one L2 channel (the panel kernel reads 64 B of each of np rows); 256 B of padding
+    // rotates consecutive rows over the channels and keeps rows 256-B aligned.
+    p.ld = p.np + 64;
     p.nthreads_panel = kPanelThreads;
     int rpt = (p.np + kPanelThreads - 1) / kPanelThreads;
     int r2 = 1;
@@ -73,7 +76,7 @@ struct BlockedWs {
 };
 static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, BlockedWs *o)
 {
-    const size_t mbytes = align256((size_t)p.np * p.np * sizeof(float));
+    const size_t mbytes = align256((size_t)p.np * p.ld * sizeof(float));
     const size_t ibytes = align256((size_t)p.np * sizeof(int) * batch);
     char *c = (char *)base;
     size_t off = 0;
@@ -94,7 +97,8 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
 size_t blocked_workspace_bytes(const BlockedPlan &p, int batch) { return blocked_carve(p, batch, nullptr, nullptr); }
 
 // ---- init: A -> diag(A, I) in the first working copy --------------------------
-__global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restrict__ in, int n, int np, size_t mstride,
+__global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restrict__ in, int n, int np, int ld,
+                                                            size_t mstride,
                                                             float *__restrict__ m0, int *__restrict__ orig,
                                                             int *__restrict__ status)
 {
@@ -111,28 +115,42 @@ __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restri
             float v;
             if (i < n && j < n) v = a[(size_t)i * n + j];
             else v = (i == j) ? 1.0f : 0.0f;
-            m[(size_t)i * np + j] = v;
+            m[(size_t)i * ld + j] = v;
         }
     }
     if (blockIdx.y == 0 && j < np) orig[(size_t)b * np + j] = j;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status) status[b] = MI32_OK;
 }
 
-// ---- wave-level arg-max helpers ------------------------------------------------
-__device__ __forceinline__ float wave_max_f32(float v)
+// ---- wave-level arg-max helpers (DPP, no LDS traffic) ----------------------------
+// Canonical gfx9 wave64 reduction: quad_perm x2, row_half_mirror, row_mirror, then
+// row_bcast15 / row_bcast31 fold the four rows; lane 63 ends up with the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
-__device__ __forceinline__ int wave_min_i32(int v)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
+    unsigned t;
+    t = dpp_u32<0xB1, 0xF>(v); v = t > v ? t : v;   // quad_perm [1,0,3,2]
+    t = dpp_u32<0x4E, 0xF>(v); v = t > v ? t : v;   // quad_perm [2,3,0,1]
+    t = dpp_u32<0x141, 0xF>(v); v = t > v ? t : v;  // row_half_mirror
+    t = dpp_u32<0x140, 0xF>(v); v = t > v ? t : v;  // row_mirror
+    t = dpp_u32<0x142, 0xA>(v); v = t > v ? t : v;  // row_bcast15 -> rows 1,3
+    t = dpp_u32<0x143, 0xC>(v); v = t > v ? t : v;  // row_bcast31 -> rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    unsigned t;
+    t = dpp_u32<0xB1, 0xF>(v); v = t < v ? t : v;
+    t = dpp_u32<0x4E, 0xF>(v); v = t < v ? t : v;
+    t = dpp_u32<0x141, 0xF>(v); v = t < v ? t : v;
+    t = dpp_u32<0x140, 0xF>(v); v = t < v ? t : v;
+    t = dpp_u32<0x142, 0xA>(v); v = t < v ? t : v;
+    t = dpp_u32<0x143, 0xC>(v); v = t < v ? t : v;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ float lane_bcast(float v, int srclane)
 {
@@ -140,64 +158,62 @@ __device__ __forceinline__ float lane_bcast(float v, int srclane)
 }
 
 // ---- the panel: W pivot steps on an (np x W) register-resident slab -----------
-// thread t owns rows t, t+512, ... (RPT of them).  src[k] tracks which row of the
-// source copy X the content now sitting in slot k came from, so the swaps never
-// touch any other column: the updates read through that map.
+// Thread t keeps rows t, t+512, ... (RPT of them) of the source copy X in registers
+// for the whole kernel: row CONTENTS never move between threads.  What a row swap
+// changes is only an integer label pos[k] = the position (row index of the working
+// matrix) that the content of register row k currently occupies:
+//   pivotElements (mat_inv_32.cpp:154-173)  ==  exchange of two labels.
+// The permutation becomes real when the slab is stored: register row k goes to row
+// pos[k] of the destination copy Y, and submap[pos[k]] = its row in X tells the
+// rank-k updates where every other column's data for that position still lives.
 template <int W>
-struct PanelShared {
-    float prow[W];
-    float arow[W];
-    int psrc, asrc;
-    float wv[kPanelWaves];
-    int wi[kPanelWaves];
+struct __attribute__((aligned(16))) PanelShared {
+    float prow[W];              // the pivot row as found (un-normalised)
+    unsigned long long key[W];  // one cross-wave arg-max word per step, zeroed at kernel start
 };
 
-// One pivot step; R is a template parameter so that every index into the
-// register slab is a compile-time constant (a runtime index would send the
-// whole slab to scratch memory).
+// One pivot step; R is a template parameter so that every index into the register
+// slab is a compile-time constant (a runtime index would send the slab to scratch).
 template <int RPT, int W, int R>
-__device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&src)[RPT], PanelShared<W> &sh, int tid, int ld,
-                                           int c0, bool &singular)
+__device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], PanelShared<W> &sh, int tid, int nrows,
+                                           int n, int c0, bool &singular)
 {
     const int lane = tid & 63;
-    const int wave = tid >> 6;
     const int slot = c0 + R;
-    // -- maxPivot: rows >= slot, first maximum of |a| wins, NaN never wins
-    float bv = -1.0f;
-    int bi = 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int row = tid + k * kPanelThreads;
-        const float v = __builtin_fabsf(a[k][R]);
-        if (row >= slot && row < ld && v > bv) { bv = v; bi = row; }  // NaN: v > bv is false
-    }
-    const float wv = wave_max_f32(bv);
-    const int wi = wave_min_i32(bv == wv ? bi : 0x7fffffff);
-    if (lane == 0) { sh.wv[wave] = wv; sh.wi[wave] = wi; }
-    __syncthreads();
-    float gv = sh.wv[0];
-    int gi = sh.wi[0];
-#pragma unroll
-    for (int q = 1; q < kPanelWaves; ++q) {
-        const float v = sh.wv[q];
-        const int i = sh.wi[q];
-        if (v > gv || (v == gv && i < gi)) { gv = v; gi = i; }
-    }
-    const int p = (gv < 0.0f) ? slot : gi;
+    // a real column may only take its pivot from the real rows: the identity padding must never be
+    // swapped into the matrix (it would be, on an all-zero/NaN column, where every candidate ties at 0)
+    const unsigned span = (unsigned)((slot < n ? n : nrows) - slot);
 
-    // -- pivotElements: publish rows p and slot (the swap is the exchange below)
+    // -- maxPivot: positions >= slot, largest |a|, lowest position among equals, NaN never wins.
+    //    |a| >= 0, so its bit pattern orders like the value: integer max/min on the bits.
+    unsigned bm = 0u, bi = 0x7fffffffu;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int row = tid + k * kPanelThreads;
-        if (row == p) {
+        const float v = __builtin_fabsf(a[k][R]);
+        const unsigned m = __float_as_uint(v);
+        const bool ok = ((unsigned)(pos[k] - slot) < span) && (v == v);
+        const bool take = ok && ((bi == 0x7fffffffu) || (m > bm) || (m == bm && (unsigned)pos[k] < bi));
+        bm = take ? m : bm;
+        bi = take ? (unsigned)pos[k] : bi;
+    }
+    const unsigned wm = wave_max_u32(bm);
+    const unsigned wi = wave_min_u32((bm == wm) ? bi : 0x7fffffffu);
+    if (lane == 0) atomicMax(&sh.key[R], ((unsigned long long)wm << 32) | (unsigned long long)(0xFFFFFFFFu - wi));
+    __syncthreads();
+    const unsigned long long key = sh.key[R];
+    const unsigned pidx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+    const int p = (pidx == 0x7fffffffu) ? slot : (int)pidx;  // no candidate at all: keep the slot's own row
+
+    // -- the holder of position p publishes its row (only that wave enters the block)
 #pragma unroll
-            for (int c = 0; c < W; ++c) sh.prow[c] = a[k][c];
-            sh.psrc = src[k];
-        }
-        if (row == slot && p != slot) {
+    for (int k = 0; k < RPT; ++k) {
+        const bool mine = (pos[k] == p);
+        if (__any(mine)) {
+            if (mine) {
 #pragma unroll
-            for (int c = 0; c < W; ++c) sh.arow[c] = a[k][c];
-            sh.asrc = src[k];
+                for (int c = 0; c < W; c += 4)
+                    *reinterpret_cast<float4 *>(&sh.prow[c]) = make_float4(a[k][c], a[k][c + 1], a[k][c + 2], a[k][c + 3]);
+            }
         }
     }
     __syncthreads();
@@ -212,40 +228,40 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&src)[RPT], 
     for (int c = 0; c < W; ++c) prn[c] = lane_bcast(qv, c);
     if (piv == 0.0f || piv != piv) singular = true;
 
-    // -- fixColumn on the slab
+    // -- fixColumn on the slab, branch-free (the pivot row itself is overwritten right after)
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int row = tid + k * kPanelThreads;
-        if (row == slot) {
+        const float f = a[k][R];
+        a[k][R] = 0.0f;
 #pragma unroll
-            for (int c = 0; c < W; ++c) a[k][c] = prn[c];
-            src[k] = sh.psrc;
-        } else {
-            if (row == p) {  // p != slot here: this slot receives the old row `slot`
+        for (int c = 0; c < W; ++c) a[k][c] = __builtin_fmaf(-f, prn[c], a[k][c]);
+    }
+    // -- pivot row := normalised pivot row; pivotElements == exchange of the two position labels
 #pragma unroll
-                for (int c = 0; c < W; ++c) a[k][c] = sh.arow[c];
-                src[k] = sh.asrc;
+    for (int k = 0; k < RPT; ++k) {
+        const bool mine = (pos[k] == p);
+        if (__any(mine)) {
+            if (mine) {
+#pragma unroll
+                for (int c = 0; c < W; ++c) a[k][c] = prn[c];
             }
-            const float f = a[k][R];
-            a[k][R] = 0.0f;
-#pragma unroll
-            for (int c = 0; c < W; ++c) a[k][c] = __builtin_fmaf(-f, prn[c], a[k][c]);
         }
+        pos[k] = mine ? slot : ((pos[k] == slot) ? p : pos[k]);
     }
 }
 
 template <int RPT, int W, int R>
 struct PanelSteps {
-    static __device__ __forceinline__ void run(float (&a)[RPT][W], int (&src)[RPT], PanelShared<W> &sh, int tid,
-                                               int ld, int c0, bool &singular)
+    static __device__ __forceinline__ void run(float (&a)[RPT][W], int (&pos)[RPT], PanelShared<W> &sh, int tid,
+                                               int nrows, int n, int c0, bool &singular)
     {
-        panel_step<RPT, W, R>(a, src, sh, tid, ld, c0, singular);
-        PanelSteps<RPT, W, R + 1>::run(a, src, sh, tid, ld, c0, singular);
+        panel_step<RPT, W, R>(a, pos, sh, tid, nrows, n, c0, singular);
+        PanelSteps<RPT, W, R + 1>::run(a, pos, sh, tid, nrows, n, c0, singular);
     }
 };
 template <int RPT, int W>
 struct PanelSteps<RPT, W, W> {
-    static __device__ __forceinline__ void run(float (&)[RPT][W], int (&)[RPT], PanelShared<W> &, int, int, int,
+    static __device__ __forceinline__ void run(float (&)[RPT][W], int (&)[RPT], PanelShared<W> &, int, int, int, int,
                                                bool &)
     {
     }
@@ -253,8 +269,9 @@ struct PanelSteps<RPT, W, W> {
 
 template <int RPT, int W>
 __global__ __launch_bounds__(kPanelThreads) void gj_panel_kernel(const float *__restrict__ x_all,
-                                                                  float *__restrict__ y_all, int ld, size_t mstride,
-                                                                  int c0, int *__restrict__ submap_all,
+                                                                  float *__restrict__ y_all, int np, int ld, int n,
+                                                                  size_t mstride, int c0,
+                                                                  int *__restrict__ submap_all,
                                                                   int *__restrict__ rowsrc_all,
                                                                   int *__restrict__ orig_all, int first_in_block,
                                                                   int *__restrict__ status)
@@ -264,14 +281,16 @@ __global__ __launch_bounds__(kPanelThreads) void gj_panel_kernel(const float *__
     const int tid = threadIdx.x;
     const float *x = x_all + (size_t)b * mstride;
     float *y = y_all + (size_t)b * mstride;
+    if (tid < W) sh.key[tid] = 0ull;
 
     float a[RPT][W];
-    int src[RPT];
+    int pos[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int row = tid + k * kPanelThreads;
-        src[k] = row;
-        if (row < ld) {
+        // rows beyond the matrix (only when np is not a multiple of 512) get a label no step can match
+        pos[k] = row < np ? row : 0x40000000 + row;
+        if (row < np) {
 #pragma unroll
             for (int c = 0; c < W; c += 4) {
                 const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)row * ld + c0 + c);
@@ -283,33 +302,34 @@ __global__ __launch_bounds__(kPanelThreads) void gj_panel_kernel(const float *__
         }
     }
     bool singular = false;
-    PanelSteps<RPT, W, 0>::run(a, src, sh, tid, ld, c0, singular);
+    __syncthreads();  // sh.key[] zeroed before any wave's first atomicMax
+    PanelSteps<RPT, W, 0>::run(a, pos, sh, tid, np, n, c0, singular);
 
-    // -- write G_s and the row maps
-    int *submap = submap_all + (size_t)b * ld;
-    int *rowsrc = rowsrc_all + (size_t)b * ld;
-    int *orig = orig_all + (size_t)b * ld;
+    // -- store G_s through the permutation and publish the row maps
+    int *submap = submap_all + (size_t)b * np;
+    int *rowsrc = rowsrc_all + (size_t)b * np;
+    int *orig = orig_all + (size_t)b * np;
     int nrs[RPT], nor[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int row = tid + k * kPanelThreads;
-        if (row < ld) {
+        if (row < np) {
 #pragma unroll
             for (int c = 0; c < W; c += 4)
-                *reinterpret_cast<float4 *>(y + (size_t)row * ld + c0 + c) =
+                *reinterpret_cast<float4 *>(y + (size_t)pos[k] * ld + c0 + c) =
                     make_float4(a[k][c], a[k][c + 1], a[k][c + 2], a[k][c + 3]);
-            submap[row] = src[k];
-            nrs[k] = first_in_block ? src[k] : rowsrc[src[k]];
-            nor[k] = orig[src[k]];
+            submap[pos[k]] = row;                            // position pos[k] now holds X's row `row`
+            nrs[k] = first_in_block ? row : rowsrc[row];     // composite map of the block so far
+            nor[k] = orig[row];
         }
     }
-    __syncthreads();
+    __syncthreads();  // every read of rowsrc/orig above precedes every write below
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int row = tid + k * kPanelThreads;
-        if (row < ld) {
-            rowsrc[row] = nrs[k];
-            orig[row] = nor[k];
+        if (row < np) {
+            rowsrc[pos[k]] = nrs[k];
+            orig[pos[k]] = nor[k];
         }
     }
     if (singular && tid == 0 && status) status[b] = MI32_SINGULAR;
@@ -326,8 +346,8 @@ __global__ __launch_bounds__(kPanelThreads) void gj_panel_kernel(const float *__
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__restrict__ src_all,
                                                               float *__restrict__ dst_all,
-                                                              const float *__restrict__ g_all, int ld, size_t mstride,
-                                                              int c0, int kdim, int col_lo,
+                                                              const float *__restrict__ g_all, int np, int ld,
+                                                              size_t mstride, int c0, int kdim, int col_lo,
                                                               const int *__restrict__ map_all, int copy_panel)
 {
     constexpr int WM = BM / 2, WN = BN / 2;
@@ -349,7 +369,7 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     const float *src = src_all + (size_t)b * mstride;
     float *dst = dst_all + (size_t)b * mstride;
     const float *g = g_all + (size_t)b * mstride;
-    const int *map = map_all + (size_t)b * ld;
+    const int *map = map_all + (size_t)b * np;
 
     if (col0 >= c0 && col0 + BN <= c0 + kdim) {
         // tile lies inside the panel: those columns are G itself
@@ -441,22 +461,22 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
 }
 
 // ---- getInvertedMatrix counterpart: undo the column permutation ----------------
-__global__ void invert_perm_ld_kernel(const int *__restrict__ orig, int *__restrict__ invp, int n, int ld)
+__global__ void invert_perm_ld_kernel(const int *__restrict__ orig, int *__restrict__ invp, int n, int istride)
 {
     const int b = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n) invp[(size_t)b * ld + orig[(size_t)b * ld + c]] = c;
+    if (c < n) invp[(size_t)b * istride + orig[(size_t)b * istride + c]] = c;
 }
 __global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *__restrict__ w_all, int ld,
                                                                     size_t wstride, const int *__restrict__ invp,
-                                                                    int n, float *__restrict__ out)
+                                                                    int istride, int n, float *__restrict__ out)
 {
     const int b = blockIdx.z;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const float *w = w_all + (size_t)b * wstride;
     float *o = out + (size_t)b * n * n;
-    const int c = invp[(size_t)b * ld + j];
+    const int c = invp[(size_t)b * istride + j];
     const int i0 = blockIdx.y * 16;
 #pragma unroll 4
     for (int u = 0; u < 16; ++u) {
@@ -466,11 +486,11 @@ __global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *
 }
 
 template <int RPT, int W>
-static void launch_panel(const BlockedWs &ws, const float *x, float *y, int np, int c0, int first, int batch,
-                         int *d_status, hipStream_t stream)
+static void launch_panel(const BlockedWs &ws, const float *x, float *y, int np, int ld, int n, int c0, int first,
+                         int batch, int *d_status, hipStream_t stream)
 {
-    hipLaunchKernelGGL((gj_panel_kernel<RPT, W>), dim3(batch), dim3(kPanelThreads), 0, stream, x, y, np, ws.mstride,
-                       c0, ws.submap, ws.rowsrc, ws.orig, first, d_status);
+    hipLaunchKernelGGL((gj_panel_kernel<RPT, W>), dim3(batch), dim3(kPanelThreads), 0, stream, x, y, np, ld, n,
+                       ws.mstride, c0, ws.submap, ws.rowsrc, ws.orig, first, d_status);
 }
 
 static void dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, const float *x, float *y, int c0, int first,
@@ -478,7 +498,7 @@ static void dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, const floa
 {
 #define MI32_PANEL_CASE(R, WW)                                                  \
     if (p.rpt == R && p.w == WW) {                                              \
-        launch_panel<R, WW>(ws, x, y, p.np, c0, first, batch, d_status, stream); \
+        launch_panel<R, WW>(ws, x, y, p.np, p.ld, p.n, c0, first, batch, d_status, stream); \
         return;                                                                 \
     }
     MI32_PANEL_CASE(1, 16) MI32_PANEL_CASE(2, 16) MI32_PANEL_CASE(4, 16) MI32_PANEL_CASE(8, 16)
@@ -494,13 +514,16 @@ static void launch_inner_update(const BlockedPlan &p, const BlockedWs &ws, const
     // columns [C0, C0+kb) of the block, K = w
     const dim3 grid(kb / 64, p.np / 64, batch);
     if (p.w == 16)
-        hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 16>), grid, dim3(256), 0, stream, x, y, y, p.np, ws.mstride,
+        hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 16>), grid, dim3(256), 0, stream, x, y, y, p.np, p.ld,
+                           ws.mstride,
                            c0, 16, C0, ws.submap, 0);
     else if (p.w == 8)
-        hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 8>), grid, dim3(256), 0, stream, x, y, y, p.np, ws.mstride,
+        hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 8>), grid, dim3(256), 0, stream, x, y, y, p.np, p.ld,
+                           ws.mstride,
                            c0, 8, C0, ws.submap, 0);
     else
-        hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 4>), grid, dim3(256), 0, stream, x, y, y, p.np, ws.mstride,
+        hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 4>), grid, dim3(256), 0, stream, x, y, y, p.np, p.ld,
+                           ws.mstride,
                            c0, 4, C0, ws.submap, 0);
 }
 
@@ -513,7 +536,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     {
         ProfScope ps(prof, KC_INIT, stream);
         hipLaunchKernelGGL(blocked_init_kernel, dim3((np + 255) / 256, (np + 15) / 16, batch), dim3(256), 0, stream,
-                           d_a, p.n, np, ws.mstride, ws.m0, ws.orig, d_status);
+                           d_a, p.n, np, p.ld, ws.mstride, ws.m0, ws.orig, d_status);
     }
     float *cur = ws.m0, *oth = ws.m1;
     for (int C0 = 0; C0 < np; C0 += p.bw) {
@@ -536,17 +559,18 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
             const dim3 grid(np / 128, np / 128, batch);
             ProfScope ps(prof, KC_UPDATE_OUT, stream);
             hipLaunchKernelGGL((gj_rank_update_kernel<128, 128, 32>), grid, dim3(256), 0, stream, cur, oth, x, np,
-                               ws.mstride, C0, kb, 0, ws.rowsrc, (x != oth) ? 1 : 0);
+                               p.ld, ws.mstride, C0, kb, 0, ws.rowsrc, (x != oth) ? 1 : 0);
             float *t = cur; cur = oth; oth = t;
         } else {
             cur = x;  // single block: the panel is the whole matrix
         }
     }
     ProfScope ps(prof, KC_FINISH, stream);
-    hipLaunchKernelGGL(invert_perm_ld_kernel, dim3((p.n + 255) / 256, batch), dim3(256), 0, stream, ws.orig, ws.invp,
-                       p.n, np);
+    // over ALL np entries: orig is a permutation of [0, np), so every invp[j] is defined and in range
+    hipLaunchKernelGGL(invert_perm_ld_kernel, dim3((np + 255) / 256, batch), dim3(256), 0, stream, ws.orig, ws.invp,
+                       np, np);
     hipLaunchKernelGGL(unpermute_columns_ld_kernel, dim3((p.n + 255) / 256, (p.n + 15) / 16, batch), dim3(256), 0,
-                       stream, cur, np, ws.mstride, ws.invp, p.n, d_inv);
+                       stream, cur, p.ld, ws.mstride, ws.invp, np, p.n, d_inv);
     return hipGetLastError();
 }
 

@@ -65,6 +65,7 @@ struct EventProfiler : public Profiler {
 struct mi32_context {
     int device = 0;
     EventProfiler *prof = nullptr;
+    hipEvent_t switch_event = nullptr;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     void *ws = nullptr;
@@ -174,6 +175,7 @@ int mi32_destroy(mi32_handle_t h)
     if (h->d_out) (void)hipFree(h->d_out);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->switch_event) (void)hipEventDestroy(h->switch_event);
     delete h->prof;
     delete h;
     return MI32_OK;
@@ -183,7 +185,16 @@ int mi32_set_stream(mi32_handle_t h, void *hip_stream)
 {
     if (!h) return MI32_BAD_SHAPE;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    hipStream_t ns = (hipStream_t)hip_stream;  // NULL is a stream too: HIP's default stream
+    if (ns != h->stream) {
+        // the workspace is shared by every call on this context: work enqueued on the new stream
+        // must wait for what is still running on the old one
+        MI32_HIP(hipSetDevice(h->device));
+        if (!h->switch_event) MI32_HIP(hipEventCreateWithFlags(&h->switch_event, hipEventDisableTiming));
+        MI32_HIP(hipEventRecord(h->switch_event, h->stream));
+        MI32_HIP(hipStreamWaitEvent(ns, h->switch_event, 0));
+        h->stream = ns;
+    }
     return MI32_OK;
 }
 

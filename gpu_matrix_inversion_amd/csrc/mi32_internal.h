@@ -71,6 +71,7 @@ struct SweepPlan {
 struct BlockedPlan {
     int n;     // matrix order
     int np;    // padded order (multiple of 128), identity padding
+    int ld;    // row stride of the working copies in floats (np + 64)
     int w;     // sub-panel width
     int bw;    // outer block width
     int nthreads_panel;

@@ -62,8 +62,9 @@ int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int
 /* ---- context ------------------------------------------------------------- */
 int mi32_create(mi32_handle_t *out, int device /* HIP ordinal, <0 = current */);
 int mi32_destroy(mi32_handle_t h);
-/* hipStream_t on which every launch of this context is enqueued (NULL = the
- * context's own stream).  The caller keeps ownership. */
+/* hipStream_t on which every launch of this context is enqueued from now on; NULL is
+ * HIP's default stream.  A new context starts on a non-blocking stream of its own.  The
+ * caller keeps ownership of the stream it passes. */
 int mi32_set_stream(mi32_handle_t h, void *hip_stream);
 int mi32_set_algo(mi32_handle_t h, int algo);
 /* tuning knobs of the blocked path: sub-panel width (8/16/32) and the outer
