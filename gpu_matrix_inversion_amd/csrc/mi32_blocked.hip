@@ -9,10 +9,11 @@
 //     for each sub-panel Ks = [c0, c0+W) of K:
 //       gj_panel_kernel     -- ONE workgroup per matrix holds all rows of the W
 //                              sub-panel columns in registers and runs the W
-//                              pivot steps on them: column arg-max (wave64 shuffle
-//                              + LDS), row swap, IEEE-division normalise,
-//                              eliminate.  Result: G_s = the W transformed
-//                              columns (the inverse columns of these pivots).
+//                              pivot steps on them: column arg-max (DPP + one LDS
+//                              atomic), row swap (= exchange of two position
+//                              labels), IEEE-division normalise, eliminate.
+//                              Result: G_s = the W transformed columns (the
+//                              inverse columns of these pivots).
 //       gj_rank_update_kernel (K = W)  -- every other column j of the block:
 //                              M[i][j] = (i in Ks ? 0 : M[src(i)][j])
 //                                        + sum_k G_s[i][k] * M[src(c0+k)][j]
@@ -26,40 +27,59 @@
 // The two working copies alternate roles exactly like the reference's
 // ping-pong buffers (mat_inv_32.cpp:318,353-360).
 //
+// The panel kernel is a single workgroup on the critical path of all N pivot
+// steps, so it only ever touches COMPACT, TRANSPOSED panels: it reads
+// Pt[c][row] (W x np, written by whichever wide kernel produced those columns)
+// and writes Gt[c][row], both with fully coalesced 16-byte accesses.  The wide
+// update kernels, which hold those values anyway, export the next sub-panel's
+// columns into Pt and materialise G_s into the row-major matrix.  (Letting the
+// one workgroup gather 64-byte chunks of np rows itself cost 18 us per launch,
+// more than its 16 pivot steps.)
+//
 // The working matrix is the N x N in-place form (see mi32_sweep.hip), padded
 // with an identity block to a multiple of 128 so that no tile needs bounds
-// checks: inv(diag(A, I)) = diag(inv(A), I), and the padding rows are exact
-// zeros in every real column, so they can never win a pivot search.
+// checks: inv(diag(A, I)) = diag(inv(A), I); a real column only ever takes its
+// pivot from the real rows, so the padding is never swapped into the matrix.
+#include <cstdlib>
+
 #include "mi32_internal.h"
 
 namespace mi32 {
 
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-static constexpr int kPanelThreads = 512;
+static constexpr int kMaxW = 16;  // widest sub-panel (columns kept in registers)
 
+// Panel-kernel geometry: NT threads hold np rows x w columns in registers, rpt rows each.
+// 1024 threads (4 waves/SIMD, <= 128 VGPRs) halve every wave's per-step row work, which is what
+// the step latency is made of; below np = 2048 there are not enough rows to fill them.
 BlockedPlan make_blocked_plan(int n, int w, int bw)
 {
     BlockedPlan p;
     p.n = n;
     p.np = (n + 127) & ~127;
-    // Row stride: np + 64 floats.  A power-of-two stride would put the same column chunk of every
-    // row on one L2 channel (the panel kernel reads 64 B of each of np rows); 256 B of padding
-    // rotates consecutive rows over the channels and keeps rows 256-B aligned.
+    // Row stride: np + 64 floats (256 B): keeps rows 256-B aligned and avoids a power-of-two stride.
     p.ld = p.np + 64;
-    p.nthreads_panel = kPanelThreads;
-    int rpt = (p.np + kPanelThreads - 1) / kPanelThreads;
-    int r2 = 1;
-    while (r2 < rpt) r2 *= 2;
-    p.rpt = r2;
-    // registers: rpt * w floats per thread must stay <= 128
-    int wmax = 128 / r2;
-    if (wmax > 16) wmax = 16;
-    if (wmax < 4) wmax = 4;
+    int nt = (p.np >= 2048) ? 1024 : 512;
+    if (const char *e = std::getenv("MI32_PANEL_THREADS")) {
+        const int v = std::atoi(e);
+        if (v == 512 || v == 1024) nt = v;
+    }
+    int rpt = 1;
+    while (rpt * nt < p.np) rpt *= 2;
+    if (rpt * 4 > 128 && nt == 512) {  // does not fit with 512 threads: use 1024
+        nt = 1024;
+        rpt = 1;
+        while (rpt * nt < p.np) rpt *= 2;
+    }
+    p.nthreads_panel = nt;
+    p.rpt = rpt;
+    int wmax = ((nt == 1024) ? 64 : 128) / rpt;  // floats of slab per thread
+    if (wmax > kMaxW) wmax = kMaxW;
     if (w <= 0) w = 16;
     if (w > wmax) w = wmax;
-    if (w != 4 && w != 8 && w != 16) w = (w > 8) ? 16 : (w > 4 ? 8 : 4);
-    p.w = w;
+    w = (w >= 16) ? 16 : (w >= 8 ? 8 : 4);
+    p.w = w;  // wmax < 4 (np > 16384) is rejected by blocked_supported()
     if (bw <= 0) bw = 256;
     bw = (bw + 127) & ~127;
     if (bw > 512) bw = 512;
@@ -67,23 +87,31 @@ BlockedPlan make_blocked_plan(int n, int w, int bw)
     p.bw = bw;
     return p;
 }
+bool blocked_supported(int n) { return n > 0 && ((n + 127) & ~127) <= 16384; }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct BlockedWs {
-    float *m0, *m1;
+    float *m0, *m1;   // the two working copies, np x ld each
+    float *pt, *gt;   // compact transposed panels, kMaxW x np each: panel kernel input / output
     int *submap, *rowsrc, *orig, *invp;
-    size_t mstride;
+    size_t mstride;   // floats per matrix in m0/m1
+    size_t tstride;   // floats per matrix in pt/gt
 };
 static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, BlockedWs *o)
 {
     const size_t mbytes = align256((size_t)p.np * p.ld * sizeof(float));
+    const size_t tbytes = align256((size_t)kMaxW * p.np * sizeof(float));
     const size_t ibytes = align256((size_t)p.np * sizeof(int) * batch);
     char *c = (char *)base;
     size_t off = 0;
-    if (o) { o->m0 = (float *)(c + off); o->mstride = mbytes / sizeof(float); }
+    if (o) { o->m0 = (float *)(c + off); o->mstride = mbytes / sizeof(float); o->tstride = tbytes / sizeof(float); }
     off += mbytes * batch;
     if (o) o->m1 = (float *)(c + off);
     off += mbytes * batch;
+    if (o) o->pt = (float *)(c + off);
+    off += tbytes * batch;
+    if (o) o->gt = (float *)(c + off);
+    off += tbytes * batch;
     if (o) o->submap = (int *)(c + off);
     off += ibytes;
     if (o) o->rowsrc = (int *)(c + off);
@@ -96,17 +124,19 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
 }
 size_t blocked_workspace_bytes(const BlockedPlan &p, int batch) { return blocked_carve(p, batch, nullptr, nullptr); }
 
-// ---- init: A -> diag(A, I) in the first working copy --------------------------
+// ---- init: A -> diag(A, I) in the first working copy (makeAugmentedMatrix counterpart,
+//      mat_inv_32.cpp:177-192) + the compact copy of the first sub-panel's columns ---------
 __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restrict__ in, int n, int np, int ld,
-                                                            size_t mstride,
-                                                            float *__restrict__ m0, int *__restrict__ orig,
-                                                            int *__restrict__ status)
+                                                            size_t mstride, float *__restrict__ m0,
+                                                            float *__restrict__ pt_all, size_t tstride, int w,
+                                                            int *__restrict__ orig, int *__restrict__ status)
 {
     const int b = blockIdx.z;
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int i0 = blockIdx.y * 16;
     const float *a = in + (size_t)b * n * n;
     float *m = m0 + (size_t)b * mstride;
+    float *pt = pt_all + (size_t)b * tstride;
     if (j < np) {
 #pragma unroll 4
         for (int u = 0; u < 16; ++u) {
@@ -116,6 +146,7 @@ __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restri
             if (i < n && j < n) v = a[(size_t)i * n + j];
             else v = (i == j) ? 1.0f : 0.0f;
             m[(size_t)i * ld + j] = v;
+            if (j < w) pt[(size_t)j * np + i] = v;
         }
     }
     if (blockIdx.y == 0 && j < np) orig[(size_t)b * np + j] = j;
@@ -124,32 +155,32 @@ __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restri
 
 // ---- wave-level arg-max helpers (DPP, no LDS traffic) ----------------------------
 // Canonical gfx9 wave64 reduction: quad_perm x2, row_half_mirror, row_mirror, then
-// row_bcast15 / row_bcast31 fold the four rows; lane 63 ends up with the total.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v)
-{
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
+// row_bcast15 / row_bcast31 fold the four rows; lane 63 ends up with the total.  Each stage
+// is ONE instruction (v_max_u32 / v_min_u32 with a DPP source); hipcc's update_dpp builtin
+// emits v_mov_dpp + op + copy per stage, and this chain sits on the critical path of every
+// pivot step.  The s_nop covers the VALU-write -> DPP-read hazard (2 wait states), which the
+// compiler does not pad inside an asm statement.
+#define MI32_DPP_STAGE(OP, CTRL, V) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " CTRL : "+v"(V))
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
-    unsigned t;
-    t = dpp_u32<0xB1, 0xF>(v); v = t > v ? t : v;   // quad_perm [1,0,3,2]
-    t = dpp_u32<0x4E, 0xF>(v); v = t > v ? t : v;   // quad_perm [2,3,0,1]
-    t = dpp_u32<0x141, 0xF>(v); v = t > v ? t : v;  // row_half_mirror
-    t = dpp_u32<0x140, 0xF>(v); v = t > v ? t : v;  // row_mirror
-    t = dpp_u32<0x142, 0xA>(v); v = t > v ? t : v;  // row_bcast15 -> rows 1,3
-    t = dpp_u32<0x143, 0xC>(v); v = t > v ? t : v;  // row_bcast31 -> rows 2,3
+    MI32_DPP_STAGE("v_max_u32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", v);
+    MI32_DPP_STAGE("v_max_u32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf", v);
+    MI32_DPP_STAGE("v_max_u32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf", v);
+    MI32_DPP_STAGE("v_max_u32_dpp", "row_mirror row_mask:0xf bank_mask:0xf", v);
+    MI32_DPP_STAGE("v_max_u32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf", v);
+    MI32_DPP_STAGE("v_max_u32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf", v);
+    asm volatile("s_nop 1" :::);
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
-    unsigned t;
-    t = dpp_u32<0xB1, 0xF>(v); v = t < v ? t : v;
-    t = dpp_u32<0x4E, 0xF>(v); v = t < v ? t : v;
-    t = dpp_u32<0x141, 0xF>(v); v = t < v ? t : v;
-    t = dpp_u32<0x140, 0xF>(v); v = t < v ? t : v;
-    t = dpp_u32<0x142, 0xA>(v); v = t < v ? t : v;
-    t = dpp_u32<0x143, 0xC>(v); v = t < v ? t : v;
+    MI32_DPP_STAGE("v_min_u32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", v);
+    MI32_DPP_STAGE("v_min_u32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf", v);
+    MI32_DPP_STAGE("v_min_u32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf", v);
+    MI32_DPP_STAGE("v_min_u32_dpp", "row_mirror row_mask:0xf bank_mask:0xf", v);
+    MI32_DPP_STAGE("v_min_u32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf", v);
+    MI32_DPP_STAGE("v_min_u32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf", v);
+    asm volatile("s_nop 1" :::);
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ float lane_bcast(float v, int srclane)
@@ -158,197 +189,279 @@ __device__ __forceinline__ float lane_bcast(float v, int srclane)
 }
 
 // ---- the panel: W pivot steps on an (np x W) register-resident slab -----------
-// Thread t keeps rows t, t+512, ... (RPT of them) of the source copy X in registers
-// for the whole kernel: row CONTENTS never move between threads.  What a row swap
-// changes is only an integer label pos[k] = the position (row index of the working
-// matrix) that the content of register row k currently occupies:
+// Each thread keeps RPT rows of the panel in registers for the whole kernel: row
+// CONTENTS never move between threads.  What a row swap changes is only an integer
+// label pos[k] = the position (row index of the working matrix) that the content of
+// register row k currently occupies:
 //   pivotElements (mat_inv_32.cpp:154-173)  ==  exchange of two labels.
-// The permutation becomes real when the slab is stored: register row k goes to row
-// pos[k] of the destination copy Y, and submap[pos[k]] = its row in X tells the
-// rank-k updates where every other column's data for that position still lives.
+// submap[position] = the row of the source copy X whose data now belongs at that
+// position tells the rank-k updates where every other column's data still lives.
+
+// Diagnostic builds (tools/panel_probe.hip, -DMI32_STAMPS) record s_memtime at the phase
+// boundaries of every step; in the product build the macro expands to nothing.
+#ifdef MI32_STAMPS
+#define MI32_STAMP(step, slot_)                                                           \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (stamp_buf && threadIdx.x == 0 && blockIdx.x == 0)                             \
+            stamp_buf[(step) * 8 + (slot_)] = __builtin_amdgcn_s_memtime();               \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
+#define MI32_STAMP_PARAM , unsigned long long *stamp_buf
+#define MI32_STAMP_ARG , stamp_buf
+#else
+#define MI32_STAMP(step, slot_) do { } while (0)
+#define MI32_STAMP_PARAM
+#define MI32_STAMP_ARG
+#endif
+
 template <int W>
 struct __attribute__((aligned(16))) PanelShared {
     float prow[W];              // the pivot row as found (un-normalised)
     unsigned long long key[W];  // one cross-wave arg-max word per step, zeroed at kernel start
 };
 
-// One pivot step; R is a template parameter so that every index into the register
-// slab is a compile-time constant (a runtime index would send the slab to scratch).
-template <int RPT, int W, int R>
-__device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], PanelShared<W> &sh, int tid, int nrows,
-                                           int n, int c0, bool &singular)
+// which matrix row register row k of thread tid holds: V consecutive rows per thread so that the
+// compact panel is loaded and stored with one 4*V-byte access per column
+template <int NT, int RPT>
+__device__ __forceinline__ int panel_row(int tid, int k)
 {
+    constexpr int V = RPT < 4 ? RPT : 4;
+    return (k / V) * (V * NT) + V * tid + (k % V);
+}
+
+// One pivot step (column c0 + r of the working matrix).  With so few waves on the CU a wave
+// issues roughly one instruction per 4-8 cycles and every predicated block costs ~100 cycles
+// (s_memtime stamps), so the step keeps each wave's DEPENDENT instruction chain short: tree
+// reductions, one ballot to find the wave that holds the pivot row (the other waves skip its
+// work with a single scalar branch), branch-free elimination.
+// The step index R is a template parameter: every index into the register slab is a compile-time
+// constant, so the FMAs update the slab in place.  (A rolled loop over ext-vector rows was tried: the
+// dynamic column index made hipcc write every FMA result to a fresh register, copy all of them back and
+// spill -- 2.5x slower; the ~80 KB of straight-line code of the unrolled form is not the bottleneck.)
+template <int NT, int RPT, int W, int R>
+__device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], PanelShared<W> &sh, int tid,
+                                           int nrows, int n, int c0, bool &singular MI32_STAMP_PARAM)
+{
+    constexpr int r = R;
     const int lane = tid & 63;
-    const int slot = c0 + R;
+    const int slot = c0 + r;
     // a real column may only take its pivot from the real rows: the identity padding must never be
     // swapped into the matrix (it would be, on an all-zero/NaN column, where every candidate ties at 0)
     const unsigned span = (unsigned)((slot < n ? n : nrows) - slot);
 
     // -- maxPivot: positions >= slot, largest |a|, lowest position among equals, NaN never wins.
     //    |a| >= 0, so its bit pattern orders like the value: integer max/min on the bits.
-    unsigned bm = 0u, bi = 0x7fffffffu;
+    MI32_STAMP(r, 0);
+    float col[RPT];
+    unsigned m[RPT], id[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const float v = __builtin_fabsf(a[k][R]);
-        const unsigned m = __float_as_uint(v);
+        col[k] = a[k][r];
+        const float v = __builtin_fabsf(col[k]);
         const bool ok = ((unsigned)(pos[k] - slot) < span) && (v == v);
-        const bool take = ok && ((bi == 0x7fffffffu) || (m > bm) || (m == bm && (unsigned)pos[k] < bi));
-        bm = take ? m : bm;
-        bi = take ? (unsigned)pos[k] : bi;
+        m[k] = ok ? __float_as_uint(v) : 0u;
+        id[k] = ok ? (unsigned)pos[k] : 0x7fffffffu;
     }
+    unsigned bm = m[0];
+#pragma unroll
+    for (int k = 1; k < RPT; ++k) bm = m[k] > bm ? m[k] : bm;
+    MI32_STAMP(r, 1);
     const unsigned wm = wave_max_u32(bm);
-    const unsigned wi = wave_min_u32((bm == wm) ? bi : 0x7fffffffu);
-    if (lane == 0) atomicMax(&sh.key[R], ((unsigned long long)wm << 32) | (unsigned long long)(0xFFFFFFFFu - wi));
+    unsigned bi = 0x7fffffffu;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const unsigned c = (m[k] == wm) ? id[k] : 0x7fffffffu;
+        bi = c < bi ? c : bi;
+    }
+    const unsigned wi = wave_min_u32(bi);
+    if (lane == 0) atomicMax(&sh.key[r], ((unsigned long long)wm << 32) | (unsigned long long)(0xFFFFFFFFu - wi));
+    MI32_STAMP(r, 2);
     __syncthreads();
-    const unsigned long long key = sh.key[R];
+    const unsigned long long key = sh.key[r];
     const unsigned pidx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
     const int p = (pidx == 0x7fffffffu) ? slot : (int)pidx;  // no candidate at all: keep the slot's own row
 
-    // -- the holder of position p publishes its row (only that wave enters the block)
+    MI32_STAMP(r, 3);
+    // -- who holds position p?  one bit per register row, one ballot per wave
+    unsigned hit = 0u;
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const bool mine = (pos[k] == p);
-        if (__any(mine)) {
-            if (mine) {
+    for (int k = 0; k < RPT; ++k) hit |= (pos[k] == p) ? (1u << k) : 0u;
+    const unsigned long long holders = __ballot(hit != 0u);
+    int own_lane = -1, own_k = -1;
+    if (holders != 0ull) {  // scalar branch: exactly one wave of the block gets past this
+        own_lane = __ffsll((long long)holders) - 1;
+        own_k = __ffs((int)__builtin_amdgcn_readlane((int)hit, own_lane)) - 1;
 #pragma unroll
-                for (int c = 0; c < W; c += 4)
-                    *reinterpret_cast<float4 *>(&sh.prow[c]) = make_float4(a[k][c], a[k][c + 1], a[k][c + 2], a[k][c + 3]);
+        for (int k = 0; k < RPT; ++k)
+            if (own_k == k) {
+                if (lane == own_lane) {
+#pragma unroll
+                    for (int c = 0; c < W; c += 4)
+                        *reinterpret_cast<float4 *>(&sh.prow[c]) =
+                            make_float4(a[k][c], a[k][c + 1], a[k][c + 2], a[k][c + 3]);
+                }
             }
-        }
     }
+    MI32_STAMP(r, 4);
     __syncthreads();
+    MI32_STAMP(r, 5);
 
     // -- fixRow: lanes 0..W-1 of every wave divide one element each (IEEE), the
     //    identity entry becomes 1/piv; broadcast through SGPRs
-    const float piv = sh.prow[R];
-    const float num = (lane < W) ? ((lane == R) ? 1.0f : sh.prow[lane]) : 0.0f;
+    const float piv = sh.prow[r];
+    const float num = (lane < W) ? ((lane == r) ? 1.0f : sh.prow[lane]) : 0.0f;
     const float qv = num / piv;
     float prn[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) prn[c] = lane_bcast(qv, c);
     if (piv == 0.0f || piv != piv) singular = true;
 
+    MI32_STAMP(r, 6);
     // -- fixColumn on the slab, branch-free (the pivot row itself is overwritten right after)
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const float f = a[k][R];
-        a[k][R] = 0.0f;
+        const float f = col[k];
+        a[k][r] = 0.0f;
 #pragma unroll
         for (int c = 0; c < W; ++c) a[k][c] = __builtin_fmaf(-f, prn[c], a[k][c]);
     }
-    // -- pivot row := normalised pivot row; pivotElements == exchange of the two position labels
+    MI32_STAMP(r, 7);
+    // -- pivot row := normalised pivot row (holder wave only)
+    if (holders != 0ull) {
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const bool mine = (pos[k] == p);
-        if (__any(mine)) {
-            if (mine) {
+        for (int k = 0; k < RPT; ++k)
+            if (own_k == k) {
+                if (lane == own_lane) {
 #pragma unroll
-                for (int c = 0; c < W; ++c) a[k][c] = prn[c];
+                    for (int c = 0; c < W; ++c) a[k][c] = prn[c];
+                }
             }
-        }
-        pos[k] = mine ? slot : ((pos[k] == slot) ? p : pos[k]);
     }
+    // -- pivotElements == exchange of the two position labels
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) pos[k] = (pos[k] == p) ? slot : ((pos[k] == slot) ? p : pos[k]);
 }
 
-template <int RPT, int W, int R>
+template <int NT, int RPT, int W, int R>
 struct PanelSteps {
     static __device__ __forceinline__ void run(float (&a)[RPT][W], int (&pos)[RPT], PanelShared<W> &sh, int tid,
-                                               int nrows, int n, int c0, bool &singular)
+                                               int nrows, int n, int c0, bool &singular MI32_STAMP_PARAM)
     {
-        panel_step<RPT, W, R>(a, pos, sh, tid, nrows, n, c0, singular);
-        PanelSteps<RPT, W, R + 1>::run(a, pos, sh, tid, nrows, n, c0, singular);
+        panel_step<NT, RPT, W, R>(a, pos, sh, tid, nrows, n, c0, singular MI32_STAMP_ARG);
+        PanelSteps<NT, RPT, W, R + 1>::run(a, pos, sh, tid, nrows, n, c0, singular MI32_STAMP_ARG);
     }
 };
-template <int RPT, int W>
-struct PanelSteps<RPT, W, W> {
+template <int NT, int RPT, int W>
+struct PanelSteps<NT, RPT, W, W> {
     static __device__ __forceinline__ void run(float (&)[RPT][W], int (&)[RPT], PanelShared<W> &, int, int, int, int,
-                                               bool &)
+                                               bool & MI32_STAMP_PARAM)
     {
     }
 };
 
-template <int RPT, int W>
-__global__ __launch_bounds__(kPanelThreads) void gj_panel_kernel(const float *__restrict__ x_all,
-                                                                  float *__restrict__ y_all, int np, int ld, int n,
-                                                                  size_t mstride, int c0,
-                                                                  int *__restrict__ submap_all,
-                                                                  int *__restrict__ rowsrc_all,
-                                                                  int *__restrict__ orig_all, int first_in_block,
-                                                                  int *__restrict__ status)
+template <int NT, int RPT, int W>
+__global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ pt_all, float *__restrict__ gt_all,
+                                                       int np, int n, size_t tstride, int c0,
+                                                       int *__restrict__ submap_all, int *__restrict__ rowsrc_all,
+                                                       int *__restrict__ orig_all, int first_in_block,
+                                                       int *__restrict__ status MI32_STAMP_PARAM)
 {
+    constexpr int V = RPT < 4 ? RPT : 4;
+    typedef float vecV __attribute__((ext_vector_type(V)));
     __shared__ PanelShared<W> sh;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const float *x = x_all + (size_t)b * mstride;
-    float *y = y_all + (size_t)b * mstride;
+    const float *pt = pt_all + (size_t)b * tstride;
+    float *gt = gt_all + (size_t)b * tstride;
     if (tid < W) sh.key[tid] = 0ull;
 
     float a[RPT][W];
     int pos[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int row = tid + k * kPanelThreads;
-        // rows beyond the matrix (only when np is not a multiple of 512) get a label no step can match
-        pos[k] = row < np ? row : 0x40000000 + row;
-        if (row < np) {
+    for (int g = 0; g < RPT / V; ++g) {
+        const int row = panel_row<NT, RPT>(tid, g * V);  // first of V consecutive rows
 #pragma unroll
-            for (int c = 0; c < W; c += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)row * ld + c0 + c);
-                a[k][c] = v.x; a[k][c + 1] = v.y; a[k][c + 2] = v.z; a[k][c + 3] = v.w;
-            }
-        } else {
+        for (int c = 0; c < W; ++c) {
+            vecV v;
+            if (row < np) v = *reinterpret_cast<const vecV *>(pt + (size_t)c * np + row);
+            else v = (vecV)(0.0f);
 #pragma unroll
-            for (int c = 0; c < W; ++c) a[k][c] = 0.0f;
+            for (int j = 0; j < V; ++j) a[g * V + j][c] = v[j];
         }
+#pragma unroll
+        for (int j = 0; j < V; ++j)  // rows beyond the matrix get a label no step can match
+            pos[g * V + j] = (row + j < np) ? row + j : 0x40000000 + row + j;
     }
     bool singular = false;
     __syncthreads();  // sh.key[] zeroed before any wave's first atomicMax
-    PanelSteps<RPT, W, 0>::run(a, pos, sh, tid, np, n, c0, singular);
+    PanelSteps<NT, RPT, W, 0>::run(a, pos, sh, tid, np, n, c0, singular MI32_STAMP_ARG);
 
-    // -- store G_s through the permutation and publish the row maps
+    // -- G_s, compact and by register row (coalesced); the row maps, by position
     int *submap = submap_all + (size_t)b * np;
     int *rowsrc = rowsrc_all + (size_t)b * np;
     int *orig = orig_all + (size_t)b * np;
     int nrs[RPT], nor[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int row = tid + k * kPanelThreads;
+    for (int g = 0; g < RPT / V; ++g) {
+        const int row = panel_row<NT, RPT>(tid, g * V);
         if (row < np) {
 #pragma unroll
-            for (int c = 0; c < W; c += 4)
-                *reinterpret_cast<float4 *>(y + (size_t)pos[k] * ld + c0 + c) =
-                    make_float4(a[k][c], a[k][c + 1], a[k][c + 2], a[k][c + 3]);
-            submap[pos[k]] = row;                            // position pos[k] now holds X's row `row`
-            nrs[k] = first_in_block ? row : rowsrc[row];     // composite map of the block so far
-            nor[k] = orig[row];
+            for (int c = 0; c < W; ++c) {
+                vecV v;
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[j] = a[g * V + j][c];
+                *reinterpret_cast<vecV *>(gt + (size_t)c * np + row) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int k = g * V + j;
+                submap[pos[k]] = row + j;                            // position pos[k] now holds X's row (row + j)
+                nrs[k] = first_in_block ? row + j : rowsrc[row + j];  // composite map of the block so far
+                nor[k] = orig[row + j];
+            }
         }
     }
     __syncthreads();  // every read of rowsrc/orig above precedes every write below
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int row = tid + k * kPanelThreads;
+    for (int g = 0; g < RPT / V; ++g) {
+        const int row = panel_row<NT, RPT>(tid, g * V);
         if (row < np) {
-            rowsrc[pos[k]] = nrs[k];
-            orig[pos[k]] = nor[k];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int k = g * V + j;
+                rowsrc[pos[k]] = nrs[k];
+                orig[pos[k]] = nor[k];
+            }
         }
     }
     if (singular && tid == 0 && status) status[b] = MI32_SINGULAR;
 }
 
 // ---- rank-k update on the fp32 matrix cores ------------------------------------
-//   dst[i][j] = (i in [c0,c0+kdim) ? 0 : src[map[i]][j]) + sum_k G[i][c0+k] * src[map[c0+k]][j]
+//   dst[i][j] = (i in [c0,c0+kdim) ? 0 : src[map[i]][j]) + sum_k G[i][k] * src[map[c0+k]][j]
 // for the columns j of this tile that are not panel columns.  256 threads = 4
 // waves in a 2x2 arrangement; each wave owns (BM/2)x(BN/2) as 32x32 MFMA tiles.
-// A (= G, row-major, k contiguous) is transposed into LDS as [k][row] so that the
-// 32 lanes of a half-wave read 32 consecutive floats; B (= pivot rows, row-major)
-// is staged as it lies.  One accumulation chain per output element, k ascending:
-// bit-for-bit the fmaf chain of oracle/gj_oracle.c's blocked restatement.
-template <int BM, int BN, int BK>
+// A = G is staged into LDS as [k][row] so that the 32 lanes of a half-wave read 32
+// consecutive floats; B (= pivot rows, row-major) is staged as it lies.  One
+// accumulation chain per output element, k ascending: bit-for-bit the fmaf chain
+// of oracle/gj_oracle.c's blocked restatement.
+//
+// COMPACT_G (the in-block update, kdim == BK == w): G_s comes from the panel
+//   kernel's compact output gt[k][map[i]]; the column-tile-0 workgroups also
+//   materialise it into dst[i][c0 + k] (row-major), where every later update
+//   expects it.
+// !COMPACT_G (the rank-bw update): G is the block's panel, row-major in g_all.
+// Either flavour exports the columns [pt_col, pt_col + pt_w) it has just
+// computed into the compact transposed panel pt_out (the next sub-panel's input).
+template <int BM, int BN, int BK, bool COMPACT_G>
 __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__restrict__ src_all,
                                                               float *__restrict__ dst_all,
-                                                              const float *__restrict__ g_all, int np, int ld,
-                                                              size_t mstride, int c0, int kdim, int col_lo,
-                                                              const int *__restrict__ map_all, int copy_panel)
+                                                              const float *__restrict__ g_all, size_t gstride,
+                                                              int np, int ld, size_t mstride, int c0, int kdim,
+                                                              int col_lo, const int *__restrict__ map_all,
+                                                              int copy_panel, float *__restrict__ pt_out_all,
+                                                              size_t tstride, int pt_col, int pt_w)
 {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -368,10 +481,11 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     const int col0 = col_lo + blockIdx.x * BN;
     const float *src = src_all + (size_t)b * mstride;
     float *dst = dst_all + (size_t)b * mstride;
-    const float *g = g_all + (size_t)b * mstride;
+    const float *g = g_all + (size_t)b * gstride;
     const int *map = map_all + (size_t)b * np;
+    float *pt_out = pt_out_all + (size_t)b * tstride;
 
-    if (col0 >= c0 && col0 + BN <= c0 + kdim) {
+    if (!COMPACT_G && col0 >= c0 && col0 + BN <= c0 + kdim) {
         // tile lies inside the panel: those columns are G itself
         if (copy_panel) {
             for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
@@ -405,17 +519,29 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
         }
 
     for (int kt = 0; kt < kdim; kt += BK) {
-        // stage A: BM x BK of G, transposed
+        if constexpr (COMPACT_G) {
+            // stage A from the compact panel: gt[k][map[row]] -- already [k][row]
 #pragma unroll
-        for (int q = 0; q < (BM * BK / 4 + 255) / 256; ++q) {
-            const int idx = tid + q * 256;
-            if (idx < BM * BK / 4) {
-                const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)(row0 + rr) * ld + c0 + kt + k4);
-                s_a[(k4 + 0) * LDA + rr] = v.x;
-                s_a[(k4 + 1) * LDA + rr] = v.y;
-                s_a[(k4 + 2) * LDA + rr] = v.z;
-                s_a[(k4 + 3) * LDA + rr] = v.w;
+            for (int q = 0; q < (BM * BK + 255) / 256; ++q) {
+                const int idx = tid + q * 256;
+                if (idx < BM * BK) {
+                    const int kk = idx / BM, rr = idx % BM;
+                    s_a[kk * LDA + rr] = g[(size_t)(kt + kk) * np + s_map[rr]];
+                }
+            }
+        } else {
+            // stage A: BM x BK of the row-major panel, transposed
+#pragma unroll
+            for (int q = 0; q < (BM * BK / 4 + 255) / 256; ++q) {
+                const int idx = tid + q * 256;
+                if (idx < BM * BK / 4) {
+                    const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                    const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)(row0 + rr) * ld + c0 + kt + k4);
+                    s_a[(k4 + 0) * LDA + rr] = v.x;
+                    s_a[(k4 + 1) * LDA + rr] = v.y;
+                    s_a[(k4 + 2) * LDA + rr] = v.z;
+                    s_a[(k4 + 3) * LDA + rr] = v.w;
+                }
             }
         }
         // stage B: BK pivot rows (through the row map) x BN columns
@@ -430,6 +556,17 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
             }
         }
         __syncthreads();
+        if constexpr (COMPACT_G) {
+            // materialise G_s into the row-major working copy (column tile 0 only; kdim == BK)
+            if (blockIdx.x == 0) {
+                for (int idx = tid; idx < BM * (BK / 4); idx += 256) {
+                    const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                    *reinterpret_cast<float4 *>(dst + (size_t)(row0 + rr) * ld + c0 + k4) =
+                        make_float4(s_a[(k4 + 0) * LDA + rr], s_a[(k4 + 1) * LDA + rr], s_a[(k4 + 2) * LDA + rr],
+                                    s_a[(k4 + 3) * LDA + rr]);
+                }
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float af[TM], bf[TN];
@@ -451,11 +588,13 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int col = col0 + wc * WN + tn * 32 + lcol;
-            if (col >= c0 && col < c0 + kdim) continue;  // panel column: already holds G
+            if (col >= c0 && col < c0 + kdim) continue;  // panel column: holds G, not an update result
+            const bool exp = (col >= pt_col && col < pt_col + pt_w);  // next sub-panel's column
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int grow = row0 + wr * WM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
                 dst[(size_t)grow * ld + col] = acc[tm][tn][reg];
+                if (exp) pt_out[(size_t)(col - pt_col) * np + grow] = acc[tm][tn][reg];
             }
         }
 }
@@ -485,46 +624,49 @@ __global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *
     }
 }
 
-template <int RPT, int W>
-static void launch_panel(const BlockedWs &ws, const float *x, float *y, int np, int ld, int n, int c0, int first,
-                         int batch, int *d_status, hipStream_t stream)
+#ifndef MI32_STAMPS
+template <int NT, int RPT, int W>
+static void launch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int first, int batch, int *d_status,
+                         hipStream_t stream)
 {
-    hipLaunchKernelGGL((gj_panel_kernel<RPT, W>), dim3(batch), dim3(kPanelThreads), 0, stream, x, y, np, ld, n,
-                       ws.mstride, c0, ws.submap, ws.rowsrc, ws.orig, first, d_status);
+    hipLaunchKernelGGL((gj_panel_kernel<NT, RPT, W>), dim3(batch), dim3(NT), 0, stream, ws.pt, ws.gt, p.np, p.n,
+                       ws.tstride, c0, ws.submap, ws.rowsrc, ws.orig, first, d_status);
 }
 
-static void dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, const float *x, float *y, int c0, int first,
-                           int batch, int *d_status, hipStream_t stream)
+static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int first, int batch, int *d_status,
+                           hipStream_t stream)
 {
-#define MI32_PANEL_CASE(R, WW)                                                  \
-    if (p.rpt == R && p.w == WW) {                                              \
-        launch_panel<R, WW>(ws, x, y, p.np, p.ld, p.n, c0, first, batch, d_status, stream); \
-        return;                                                                 \
+#define MI32_PANEL_CASE(T, R, WW)                                            \
+    if (p.nthreads_panel == T && p.rpt == R && p.w == WW) {                  \
+        launch_panel<T, R, WW>(p, ws, c0, first, batch, d_status, stream);   \
+        return true;                                                         \
     }
-    MI32_PANEL_CASE(1, 16) MI32_PANEL_CASE(2, 16) MI32_PANEL_CASE(4, 16) MI32_PANEL_CASE(8, 16)
-    MI32_PANEL_CASE(1, 8) MI32_PANEL_CASE(2, 8) MI32_PANEL_CASE(4, 8) MI32_PANEL_CASE(8, 8) MI32_PANEL_CASE(16, 8)
-    MI32_PANEL_CASE(1, 4) MI32_PANEL_CASE(2, 4) MI32_PANEL_CASE(4, 4) MI32_PANEL_CASE(8, 4) MI32_PANEL_CASE(16, 4)
-    MI32_PANEL_CASE(32, 4)
+    MI32_PANEL_CASE(512, 1, 16) MI32_PANEL_CASE(512, 2, 16) MI32_PANEL_CASE(512, 4, 16) MI32_PANEL_CASE(512, 8, 16)
+    MI32_PANEL_CASE(512, 1, 8) MI32_PANEL_CASE(512, 2, 8) MI32_PANEL_CASE(512, 4, 8) MI32_PANEL_CASE(512, 8, 8)
+    MI32_PANEL_CASE(512, 1, 4) MI32_PANEL_CASE(512, 2, 4) MI32_PANEL_CASE(512, 4, 4) MI32_PANEL_CASE(512, 8, 4)
+    MI32_PANEL_CASE(1024, 1, 16) MI32_PANEL_CASE(1024, 2, 16) MI32_PANEL_CASE(1024, 4, 16)
+    MI32_PANEL_CASE(1024, 1, 8) MI32_PANEL_CASE(1024, 2, 8) MI32_PANEL_CASE(1024, 4, 8) MI32_PANEL_CASE(1024, 8, 8)
+    MI32_PANEL_CASE(1024, 1, 4) MI32_PANEL_CASE(1024, 2, 4) MI32_PANEL_CASE(1024, 4, 4) MI32_PANEL_CASE(1024, 8, 4)
+    MI32_PANEL_CASE(1024, 16, 4)
 #undef MI32_PANEL_CASE
+    return false;
 }
 
+// in-block update: columns [C0, C0+kb) of the block, K = w, G_s from the compact panel; exports the
+// next sub-panel's columns (if it lies in this block) into pt
 static void launch_inner_update(const BlockedPlan &p, const BlockedWs &ws, const float *x, float *y, int c0, int C0,
                                 int kb, int batch, hipStream_t stream)
 {
-    // columns [C0, C0+kb) of the block, K = w
     const dim3 grid(kb / 64, p.np / 64, batch);
-    if (p.w == 16)
-        hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 16>), grid, dim3(256), 0, stream, x, y, y, p.np, p.ld,
-                           ws.mstride,
-                           c0, 16, C0, ws.submap, 0);
-    else if (p.w == 8)
-        hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 8>), grid, dim3(256), 0, stream, x, y, y, p.np, p.ld,
-                           ws.mstride,
-                           c0, 8, C0, ws.submap, 0);
-    else
-        hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 4>), grid, dim3(256), 0, stream, x, y, y, p.np, p.ld,
-                           ws.mstride,
-                           c0, 4, C0, ws.submap, 0);
+    const int next = c0 + p.w;
+    const int pt_col = (next < C0 + kb) ? next : -(1 << 30);
+#define MI32_INNER(BKV)                                                                                             \
+    hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, BKV, true>), grid, dim3(256), 0, stream, x, y, ws.gt,          \
+                       ws.tstride, p.np, p.ld, ws.mstride, c0, BKV, C0, ws.submap, 0, ws.pt, ws.tstride, pt_col, p.w)
+    if (p.w == 16) MI32_INNER(16);
+    else if (p.w == 8) MI32_INNER(8);
+    else MI32_INNER(4);
+#undef MI32_INNER
 }
 
 hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *wsp,
@@ -536,7 +678,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     {
         ProfScope ps(prof, KC_INIT, stream);
         hipLaunchKernelGGL(blocked_init_kernel, dim3((np + 255) / 256, (np + 15) / 16, batch), dim3(256), 0, stream,
-                           d_a, p.n, np, p.ld, ws.mstride, ws.m0, ws.orig, d_status);
+                           d_a, p.n, np, p.ld, ws.mstride, ws.m0, ws.pt, ws.tstride, p.w, ws.orig, d_status);
     }
     float *cur = ws.m0, *oth = ws.m1;
     for (int C0 = 0; C0 < np; C0 += p.bw) {
@@ -546,9 +688,9 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
             const int c0 = C0 + s * p.w;
             {
                 ProfScope ps(prof, KC_PANEL, stream);
-                dispatch_panel(p, ws, x, y, c0, s == 0, batch, d_status, stream);
+                if (!dispatch_panel(p, ws, c0, s == 0, batch, d_status, stream)) return hipErrorInvalidValue;
             }
-            if (kb > p.w) {
+            {
                 ProfScope ps(prof, KC_UPDATE_IN, stream);
                 launch_inner_update(p, ws, x, y, c0, C0, kb, batch, stream);
             }
@@ -557,9 +699,12 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
         // x now holds the block's G; every other column is still valid in `cur` only
         if (kb < np) {
             const dim3 grid(np / 128, np / 128, batch);
+            const int next = C0 + kb;  // first sub-panel of the next block: export it into pt
+            const int pt_col = (next < np) ? next : -(1 << 30);
             ProfScope ps(prof, KC_UPDATE_OUT, stream);
-            hipLaunchKernelGGL((gj_rank_update_kernel<128, 128, 32>), grid, dim3(256), 0, stream, cur, oth, x, np,
-                               p.ld, ws.mstride, C0, kb, 0, ws.rowsrc, (x != oth) ? 1 : 0);
+            hipLaunchKernelGGL((gj_rank_update_kernel<128, 128, 32, false>), grid, dim3(256), 0, stream, cur, oth, x,
+                               ws.mstride, np, p.ld, ws.mstride, C0, kb, 0, ws.rowsrc, (x != oth) ? 1 : 0, ws.pt,
+                               ws.tstride, pt_col, p.w);
             float *t = cur; cur = oth; oth = t;
         } else {
             cur = x;  // single block: the panel is the whole matrix
@@ -573,5 +718,6 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                        stream, cur, p.ld, ws.mstride, ws.invp, np, p.n, d_inv);
     return hipGetLastError();
 }
+#endif  // !MI32_STAMPS
 
 }  // namespace mi32

@@ -105,6 +105,7 @@ static int resolve_algo(const mi32_context *h, int n)
     int algo = h ? h->algo : MI32_ALGO_AUTO;
     if (algo == MI32_ALGO_AUTO) algo = env_int("MI32_ALGO", MI32_ALGO_AUTO);
     if (algo != MI32_ALGO_SWEEP && algo != MI32_ALGO_BLOCKED) algo = (n >= 96) ? MI32_ALGO_BLOCKED : MI32_ALGO_SWEEP;
+    if (algo == MI32_ALGO_BLOCKED && !blocked_supported(n)) algo = MI32_ALGO_SWEEP;  // panel would not fit in registers
     return algo;
 }
 static BlockedPlan plan_blocked(const mi32_context *h, int n)

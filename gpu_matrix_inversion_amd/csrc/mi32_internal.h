@@ -80,6 +80,7 @@ struct BlockedPlan {
 
 SweepPlan make_sweep_plan(int n);
 BlockedPlan make_blocked_plan(int n, int w, int bw);
+bool blocked_supported(int n);  // the register-resident panel holds at most 16384 (padded) rows
 
 size_t sweep_workspace_bytes(const SweepPlan &p, int batch);
 size_t blocked_workspace_bytes(const BlockedPlan &p, int batch);

@@ -4,8 +4,11 @@ import re, subprocess, sys, os
 here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu_matrix_inversion_amd", "csrc")
 files = sys.argv[1:] or ["mi32_sweep.hip", "mi32_blocked.hip", "mi32_residual.hip"]
 for f in files:
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
-                          "-fno-fast-math", "-I../../include", "-I.", "-c", f, "-o", "/dev/null",
+    # exactly the flags of csrc/Makefile (a different flag set gives different register allocation)
+    mk = open(os.path.join(here, "Makefile")).read()
+    flags = re.search(r"^FLAGS\s*\?=\s*(.*?)(?<!\\)$", mk, re.M | re.S).group(1).replace("\\\n", " ").split()
+    flags = [fl.replace("$(ARCH)", "gfx950") for fl in flags]
+    out = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-c", f, "-o", "/dev/null",
                           "-Rpass-analysis=kernel-resource-usage"], cwd=here, capture_output=True, text=True).stderr
     cur = None
     rows = {}
