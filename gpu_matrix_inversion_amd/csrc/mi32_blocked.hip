@@ -160,27 +160,23 @@ __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restri
 // emits v_mov_dpp + op + copy per stage, and this chain sits on the critical path of every
 // pivot step.  The s_nop covers the VALU-write -> DPP-read hazard (2 wait states), which the
 // compiler does not pad inside an asm statement.
-#define MI32_DPP_STAGE(OP, CTRL, V) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " CTRL : "+v"(V))
+#define MI32_DPP_REDUCE(OP, V)                                                        \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
+                 "s_nop 1"                                                                          \
+                 : "+v"(V))
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
-    MI32_DPP_STAGE("v_max_u32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", v);
-    MI32_DPP_STAGE("v_max_u32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf", v);
-    MI32_DPP_STAGE("v_max_u32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf", v);
-    MI32_DPP_STAGE("v_max_u32_dpp", "row_mirror row_mask:0xf bank_mask:0xf", v);
-    MI32_DPP_STAGE("v_max_u32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf", v);
-    MI32_DPP_STAGE("v_max_u32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf", v);
-    asm volatile("s_nop 1" :::);
+    MI32_DPP_REDUCE("v_max_u32_dpp", v);
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
-    MI32_DPP_STAGE("v_min_u32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", v);
-    MI32_DPP_STAGE("v_min_u32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf", v);
-    MI32_DPP_STAGE("v_min_u32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf", v);
-    MI32_DPP_STAGE("v_min_u32_dpp", "row_mirror row_mask:0xf bank_mask:0xf", v);
-    MI32_DPP_STAGE("v_min_u32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf", v);
-    MI32_DPP_STAGE("v_min_u32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf", v);
-    asm volatile("s_nop 1" :::);
+    MI32_DPP_REDUCE("v_min_u32_dpp", v);
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ float lane_bcast(float v, int srclane)
@@ -203,7 +199,7 @@ __device__ __forceinline__ float lane_bcast(float v, int srclane)
 #define MI32_STAMP(step, slot_)                                                           \
     do {                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                \
-        if (stamp_buf && threadIdx.x == 0 && blockIdx.x == 0)                             \
+        if (stamp_buf && threadIdx.x == blockDim.x - 64 && blockIdx.x == 0)               \
             stamp_buf[(step) * 8 + (slot_)] = __builtin_amdgcn_s_memtime();               \
         __builtin_amdgcn_sched_barrier(0);                                                \
     } while (0)
@@ -215,10 +211,13 @@ __device__ __forceinline__ float lane_bcast(float v, int srclane)
 #define MI32_STAMP_ARG
 #endif
 
-template <int W>
+template <int NW, int W>
 struct __attribute__((aligned(16))) PanelShared {
-    float prow[W];              // the pivot row as found (un-normalised)
+    float cand[NW][W];          // per wave: its best candidate row as found (wave-private scratch)
+    float prn[2][NW][W];        // per step parity, per wave: that row NORMALISED (candidate pivot row)
+    float piv[2][NW];           // per step parity, per wave: the candidate's pivot entry
     unsigned long long key[W];  // one cross-wave arg-max word per step, zeroed at kernel start
+    int hold[W];                // which register row (as panel_row index) holds position c0 + r
 };
 
 // which matrix row register row k of thread tid holds: V consecutive rows per thread so that the
@@ -230,21 +229,43 @@ __device__ __forceinline__ int panel_row(int tid, int k)
     return (k / V) * (V * NT) + V * tid + (k % V);
 }
 
-// One pivot step (column c0 + r of the working matrix).  With so few waves on the CU a wave
-// issues roughly one instruction per 4-8 cycles and every predicated block costs ~100 cycles
-// (s_memtime stamps), so the step keeps each wave's DEPENDENT instruction chain short: tree
-// reductions, one ballot to find the wave that holds the pivot row (the other waves skip its
-// work with a single scalar branch), branch-free elimination.
-// The step index R is a template parameter: every index into the register slab is a compile-time
-// constant, so the FMAs update the slab in place.  (A rolled loop over ext-vector rows was tried: the
-// dynamic column index made hipcc write every FMA result to a fresh register, copy all of them back and
-// spill -- 2.5x slower; the ~80 KB of straight-line code of the unrolled form is not the bottleneck.)
-template <int NT, int RPT, int W, int R>
-__device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], PanelShared<W> &sh, int tid,
-                                           int nrows, int n, int c0, bool &singular MI32_STAMP_PARAM)
+// inverse of panel_row: the (thread, k) that keeps matrix row `row` of the source panel
+template <int NT, int RPT>
+__device__ __forceinline__ void panel_owner(int row, int &tid, int &k)
 {
-    constexpr int r = R;
+    constexpr int V = RPT < 4 ? RPT : 4;
+    const int g = row / (V * NT);
+    const int rem = row - g * (V * NT);
+    tid = rem / V;
+    k = g * V + (rem % V);
+}
+
+// One pivot step (column c0 + r of the working matrix) with ONE workgroup barrier.
+//
+// With so few waves on the CU the step is latency bound, not FMA bound (s_memtime stamps,
+// tools/panel_probe.hip: the 64-128 FMAs of a step take ~150 cycles, a barrier ~300, every LDS round
+// trip ~130, a taken branch into cold code ~80).  Hence:
+//  * every wave SPECULATES: it finds its own best candidate (DPP max, one ballot), normalises that row
+//    -- the identical arithmetic the winner needs: the row divided by its own pivot-column entry, 1/piv
+//    in the identity slot -- and publishes it together with its 64-bit arg-max key.  After the single
+//    barrier the key's low bits name the winning wave and its already-normalised row is read straight
+//    from LDS: no second barrier, no division on the post-barrier path, and the winning wave already
+//    knows which of its lanes/rows held the pivot;
+//  * the step body is the SAME code for every step, so the W steps are a rolled loop whose ~3 KB body
+//    is instruction-cache resident from the second iteration on (fully unrolled it was 45-80 KB of
+//    straight-line code, cold on whichever CU the one-workgroup launch landed on).  What makes that
+//    possible with compile-time register indices is a ROTATION: the FMA of column c writes its result
+//    into register c-1, so the pivot column is always register 0 and after W steps every column is back
+//    in its own register.  (Indexing the slab with the runtime step counter instead sends hipcc to
+//    scratch or to copy-heavy code.)
+template <int NT, int RPT, int W>
+__device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], PanelShared<NT / 64, W> &sh, int tid,
+                                           int nrows, int n, int c0, int r, bool wave_active,
+                                           bool &singular MI32_STAMP_PARAM)
+{
+    const int par = r & 1;
     const int lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = c0 + r;
     // a real column may only take its pivot from the real rows: the identity padding must never be
     // swapped into the matrix (it would be, on an all-zero/NaN column, where every candidate ties at 0)
@@ -252,113 +273,139 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], 
 
     // -- maxPivot: positions >= slot, largest |a|, lowest position among equals, NaN never wins.
     //    |a| >= 0, so its bit pattern orders like the value: integer max/min on the bits.
+    //    A wave all of whose rows sit above the block (position < c0) can never hold a candidate and
+    //    its labels never change: it skips the whole search with one scalar branch.
     MI32_STAMP(r, 0);
     float col[RPT];
-    unsigned m[RPT], id[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        col[k] = a[k][r];
-        const float v = __builtin_fabsf(col[k]);
-        const bool ok = ((unsigned)(pos[k] - slot) < span) && (v == v);
-        m[k] = ok ? __float_as_uint(v) : 0u;
-        id[k] = ok ? (unsigned)pos[k] : 0x7fffffffu;
-    }
-    unsigned bm = m[0];
+    for (int k = 0; k < RPT; ++k) col[k] = a[k][0];  // the pivot column is always register 0
+    int own_lane = -1, own_k = 0;
+    if (wave_active) {
+        unsigned m[RPT], id[RPT];
 #pragma unroll
-    for (int k = 1; k < RPT; ++k) bm = m[k] > bm ? m[k] : bm;
-    MI32_STAMP(r, 1);
-    const unsigned wm = wave_max_u32(bm);
-    unsigned bi = 0x7fffffffu;
+        for (int k = 0; k < RPT; ++k) {
+            const float v = __builtin_fabsf(col[k]);
+            const bool ok = ((unsigned)(pos[k] - slot) < span) && (v == v);
+            m[k] = ok ? __float_as_uint(v) : 0u;
+            id[k] = ok ? (unsigned)pos[k] : 0x7fffffffu;
+        }
+        unsigned bm = m[0];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const unsigned c = (m[k] == wm) ? id[k] : 0x7fffffffu;
-        bi = c < bi ? c : bi;
-    }
-    const unsigned wi = wave_min_u32(bi);
-    if (lane == 0) atomicMax(&sh.key[r], ((unsigned long long)wm << 32) | (unsigned long long)(0xFFFFFFFFu - wi));
-    MI32_STAMP(r, 2);
-    __syncthreads();
-    const unsigned long long key = sh.key[r];
-    const unsigned pidx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-    const int p = (pidx == 0x7fffffffu) ? slot : (int)pidx;  // no candidate at all: keep the slot's own row
-
-    MI32_STAMP(r, 3);
-    // -- who holds position p?  one bit per register row, one ballot per wave
-    unsigned hit = 0u;
+        for (int k = 1; k < RPT; ++k) bm = m[k] > bm ? m[k] : bm;
+        MI32_STAMP(r, 1);
+        const unsigned wm = wave_max_u32(bm);
+        unsigned bi = 0x7fffffffu;
+        int kb = 0;  // which of this lane's rows is its candidate
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) hit |= (pos[k] == p) ? (1u << k) : 0u;
-    const unsigned long long holders = __ballot(hit != 0u);
-    int own_lane = -1, own_k = -1;
-    if (holders != 0ull) {  // scalar branch: exactly one wave of the block gets past this
-        own_lane = __ffsll((long long)holders) - 1;
-        own_k = __ffs((int)__builtin_amdgcn_readlane((int)hit, own_lane)) - 1;
+        for (int k = 0; k < RPT; ++k) {
+            const unsigned c = (m[k] == wm) ? id[k] : 0x7fffffffu;
+            const bool take = c < bi;
+            bi = take ? c : bi;
+            kb = take ? k : kb;
+        }
+        // lowest position among the lanes that hold the wave maximum: almost always exactly one lane,
+        // which one ballot + v_readlane settle; only a genuine tie pays for a second DPP reduction
+        const unsigned long long tied = __ballot(bi != 0x7fffffffu);
+        MI32_STAMP(r, 2);
+        if (tied != 0ull) {  // this wave has a candidate
+            unsigned long long one = tied;
+            if ((tied & (tied - 1ull)) != 0ull) one = __ballot(bi == wave_min_u32(bi));
+            own_lane = __ffsll((long long)one) - 1;
+            const unsigned wi = (unsigned)__builtin_amdgcn_readlane((int)bi, own_lane);
+            own_k = __builtin_amdgcn_readlane(kb, own_lane);
+            // the candidate row, as found, into this wave's scratch slot (the holder lane writes it)
 #pragma unroll
-        for (int k = 0; k < RPT; ++k)
-            if (own_k == k) {
-                if (lane == own_lane) {
+            for (int k = 0; k < RPT; ++k)
+                if (own_k == k) {
+                    if (lane == own_lane) {
 #pragma unroll
-                    for (int c = 0; c < W; c += 4)
-                        *reinterpret_cast<float4 *>(&sh.prow[c]) =
-                            make_float4(a[k][c], a[k][c + 1], a[k][c + 2], a[k][c + 3]);
+                        for (int c = 0; c < W; c += 4)
+                            *reinterpret_cast<float4 *>(&sh.cand[wave_u][c]) =
+                                make_float4(a[k][c], a[k][c + 1], a[k][c + 2], a[k][c + 3]);
+                    }
                 }
+            // fixRow, speculatively: lanes 0..W-1 divide one element each (IEEE); identity entry -> 1/piv.
+            // The holder lane of this same wave wrote sh.cand just above: one wave's LDS operations
+            // execute in order, so no s_barrier is needed -- only the compiler must not reorder here.
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float cpiv = sh.cand[wave_u][0];
+            const float num = (lane < W) ? ((lane == 0) ? 1.0f : sh.cand[wave_u][lane]) : 0.0f;
+            const float qv = num / cpiv;
+            if (lane < W) sh.prn[par][wave_u][lane] = qv;
+            if (lane == 0) {
+                sh.piv[par][wave_u] = cpiv;
+                atomicMax(&sh.key[r], ((unsigned long long)wm << 32) |
+                                          (unsigned long long)(((0xFFFFFu - wi) << 8) | (unsigned)wave_u));
             }
+        }
     }
-    MI32_STAMP(r, 4);
+    MI32_STAMP(r, 3);
     __syncthreads();
-    MI32_STAMP(r, 5);
-
-    // -- fixRow: lanes 0..W-1 of every wave divide one element each (IEEE), the
-    //    identity entry becomes 1/piv; broadcast through SGPRs
-    const float piv = sh.prow[r];
-    const float num = (lane < W) ? ((lane == r) ? 1.0f : sh.prow[lane]) : 0.0f;
-    const float qv = num / piv;
-    float prn[W];
+    MI32_STAMP(r, 4);
+    const unsigned long long key = sh.key[r];
+    const int hs = sh.hold[r];  // the register row that currently holds position `slot`
+    const unsigned lo = (unsigned)(key & 0xFFFFFFFFull);
+    const bool none = (key == 0ull);  // no valid candidate anywhere (all-NaN column): keep the slot, flag it
+    const int p = none ? slot : (int)(0xFFFFFu - (lo >> 8));
+    const int wv = none ? -1 : (int)(lo & 0xFFu);
+    float prn[W];  // prn[0] = 1/piv (the identity column's entry), prn[c] = normalised pivot row
+    if (none) {
 #pragma unroll
-    for (int c = 0; c < W; ++c) prn[c] = lane_bcast(qv, c);
-    if (piv == 0.0f || piv != piv) singular = true;
+        for (int c = 0; c < W; ++c) prn[c] = __builtin_nanf("");
+        singular = true;
+    } else {
+#pragma unroll
+        for (int c = 0; c < W; c += 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(&sh.prn[par][wv][c]);
+            prn[c] = t.x; prn[c + 1] = t.y; prn[c + 2] = t.z; prn[c + 3] = t.w;
+        }
+        const float piv = sh.piv[par][wv];
+        if (piv == 0.0f || piv != piv) singular = true;
+    }
 
-    MI32_STAMP(r, 6);
-    // -- fixColumn on the slab, branch-free (the pivot row itself is overwritten right after)
+    MI32_STAMP(r, 5);
+    // -- fixColumn on the slab, branch-free, rotating left by one register: column c lands in register
+    //    c-1; the pivot column (register 0, the implicit identity column: entry 0 in every other row)
+    //    lands in register W-1.  The pivot row itself is overwritten right after.
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const float f = col[k];
-        a[k][r] = 0.0f;
 #pragma unroll
-        for (int c = 0; c < W; ++c) a[k][c] = __builtin_fmaf(-f, prn[c], a[k][c]);
+        for (int c = 1; c < W; ++c) a[k][c - 1] = __builtin_fmaf(-f, prn[c], a[k][c]);
+        a[k][W - 1] = __builtin_fmaf(-f, prn[0], 0.0f);
     }
-    MI32_STAMP(r, 7);
-    // -- pivot row := normalised pivot row (holder wave only)
-    if (holders != 0ull) {
+    MI32_STAMP(r, 6);
+    // -- pivot row := normalised pivot row (same rotation), and pivotElements == exchange of two
+    //    position labels.  Only two register rows of the whole block are concerned: the winner's
+    //    candidate row (its wave knows lane and row) takes label `slot`; the row that held `slot` takes p.
+    if (wave_u == wv) {
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (own_k == k) {
                 if (lane == own_lane) {
 #pragma unroll
-                    for (int c = 0; c < W; ++c) a[k][c] = prn[c];
+                    for (int c = 1; c < W; ++c) a[k][c - 1] = prn[c];
+                    a[k][W - 1] = prn[0];
+                    pos[k] = slot;
                 }
             }
     }
-    // -- pivotElements == exchange of the two position labels
+    if (p != slot) {
+        int ht, hk;
+        panel_owner<NT, RPT>(hs, ht, hk);
+        if ((ht >> 6) == wave_u) {
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) pos[k] = (pos[k] == p) ? slot : ((pos[k] == slot) ? p : pos[k]);
+            for (int k = 0; k < RPT; ++k)
+                if (hk == k) {
+                    if (lane == (ht & 63)) pos[k] = p;
+                }
+        }
+        // position p is a later slot of this panel?  then that slot is now held by the row that held `slot`
+        if (tid == 0 && p < c0 + W) sh.hold[p - c0] = hs;
+    }
+    MI32_STAMP(r, 7);
 }
-
-template <int NT, int RPT, int W, int R>
-struct PanelSteps {
-    static __device__ __forceinline__ void run(float (&a)[RPT][W], int (&pos)[RPT], PanelShared<W> &sh, int tid,
-                                               int nrows, int n, int c0, bool &singular MI32_STAMP_PARAM)
-    {
-        panel_step<NT, RPT, W, R>(a, pos, sh, tid, nrows, n, c0, singular MI32_STAMP_ARG);
-        PanelSteps<NT, RPT, W, R + 1>::run(a, pos, sh, tid, nrows, n, c0, singular MI32_STAMP_ARG);
-    }
-};
-template <int NT, int RPT, int W>
-struct PanelSteps<NT, RPT, W, W> {
-    static __device__ __forceinline__ void run(float (&)[RPT][W], int (&)[RPT], PanelShared<W> &, int, int, int, int,
-                                               bool & MI32_STAMP_PARAM)
-    {
-    }
-};
 
 template <int NT, int RPT, int W>
 __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ pt_all, float *__restrict__ gt_all,
@@ -369,12 +416,15 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ 
 {
     constexpr int V = RPT < 4 ? RPT : 4;
     typedef float vecV __attribute__((ext_vector_type(V)));
-    __shared__ PanelShared<W> sh;
+    __shared__ PanelShared<NT / 64, W> sh;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const float *pt = pt_all + (size_t)b * tstride;
     float *gt = gt_all + (size_t)b * tstride;
-    if (tid < W) sh.key[tid] = 0ull;
+    if (tid < W) {
+        sh.key[tid] = 0ull;
+        sh.hold[tid] = c0 + tid;  // no swap yet: position c0 + r sits in register row c0 + r
+    }
 
     float a[RPT][W];
     int pos[RPT];
@@ -393,15 +443,29 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ 
         for (int j = 0; j < V; ++j)  // rows beyond the matrix get a label no step can match
             pos[g * V + j] = (row + j < np) ? row + j : 0x40000000 + row + j;
     }
-    bool singular = false;
-    __syncthreads();  // sh.key[] zeroed before any wave's first atomicMax
-    PanelSteps<NT, RPT, W, 0>::run(a, pos, sh, tid, np, n, c0, singular MI32_STAMP_ARG);
-
-    // -- G_s, compact and by register row (coalesced); the row maps, by position
+    // the row maps this kernel will permute: fetched now, so their latency hides behind the steps,
+    // and parked in thread-private LDS slots (the 1024-thread instances have no registers to spare)
     int *submap = submap_all + (size_t)b * np;
     int *rowsrc = rowsrc_all + (size_t)b * np;
     int *orig = orig_all + (size_t)b * np;
-    int nrs[RPT], nor[RPT];
+    extern __shared__ int s_park[];  // [2][RPT][NT]
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int row = panel_row<NT, RPT>(tid, k);
+        s_park[k * NT + tid] = (first_in_block || row >= np) ? row : rowsrc[row];  // composite map so far
+        s_park[(RPT + k) * NT + tid] = row < np ? orig[row] : 0;
+    }
+    bool singular = false;
+    __syncthreads();  // sh.key[] zeroed before any wave's first atomicMax; all map reads issued
+    // a wave takes part in the pivot search only if at least one of its rows lies in or below the block
+    const int wave_last_tid = (__builtin_amdgcn_readfirstlane(tid) | 63);
+    const bool wave_active = panel_row<NT, RPT>(wave_last_tid, RPT - 1) >= c0;
+#pragma unroll
+    for (int r = 0; r < W; ++r)
+        panel_step<NT, RPT, W>(a, pos, sh, tid, np, n, c0, r, wave_active, singular MI32_STAMP_ARG);
+    // W rotations by one register: every column is back in its own register
+
+    // -- G_s, compact and by register row (coalesced); the row maps, by position
 #pragma unroll
     for (int g = 0; g < RPT / V; ++g) {
         const int row = panel_row<NT, RPT>(tid, g * V);
@@ -416,23 +480,15 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ 
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const int k = g * V + j;
-                submap[pos[k]] = row + j;                            // position pos[k] now holds X's row (row + j)
-                nrs[k] = first_in_block ? row + j : rowsrc[row + j];  // composite map of the block so far
-                nor[k] = orig[row + j];
+                submap[pos[k]] = row + j;  // position pos[k] now holds X's row (row + j)
             }
         }
     }
-    __syncthreads();  // every read of rowsrc/orig above precedes every write below
 #pragma unroll
-    for (int g = 0; g < RPT / V; ++g) {
-        const int row = panel_row<NT, RPT>(tid, g * V);
-        if (row < np) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const int k = g * V + j;
-                rowsrc[pos[k]] = nrs[k];
-                orig[pos[k]] = nor[k];
-            }
+    for (int k = 0; k < RPT; ++k) {
+        if (panel_row<NT, RPT>(tid, k) < np) {
+            rowsrc[pos[k]] = s_park[k * NT + tid];
+            orig[pos[k]] = s_park[(RPT + k) * NT + tid];
         }
     }
     if (singular && tid == 0 && status) status[b] = MI32_SINGULAR;
@@ -629,7 +685,8 @@ template <int NT, int RPT, int W>
 static void launch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int first, int batch, int *d_status,
                          hipStream_t stream)
 {
-    hipLaunchKernelGGL((gj_panel_kernel<NT, RPT, W>), dim3(batch), dim3(NT), 0, stream, ws.pt, ws.gt, p.np, p.n,
+    hipLaunchKernelGGL((gj_panel_kernel<NT, RPT, W>), dim3(batch), dim3(NT), 2 * RPT * NT * sizeof(int), stream, ws.pt,
+                       ws.gt, p.np, p.n,
                        ws.tstride, c0, ws.submap, ws.rowsrc, ws.orig, first, d_status);
 }
 

@@ -42,7 +42,7 @@ int main()
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0, 0));
             for (int it = 0; it < 20; ++it)
-                hipLaunchKernelGGL((gj_panel_kernel<PROBE_NT, PROBE_RPT, 16>), dim3(1), dim3(PROBE_NT), 0, 0, pt, gt, np, n,
+                hipLaunchKernelGGL((gj_panel_kernel<PROBE_NT, PROBE_RPT, 16>), dim3(1), dim3(PROBE_NT), 2 * PROBE_RPT * PROBE_NT * sizeof(int), 0, pt, gt, np, n,
                                    (size_t)W * np, 256, maps, maps + np, maps + 2 * np, 1, status, sb);
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -55,7 +55,7 @@ int main()
     printf("shader clock ~ %.0f MHz (memtime/memrealtime*100)\n", 100.0 * hc[0] / hc[1]);
     std::vector<unsigned long long> st(16 * 8);
     CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
-    const char *names[8] = {"extract+local-argmax", "wave-reduce+atomic", "barrier1+key", "find-holder+publish", "barrier2", "divide+bcast", "eliminate", "fixup+labels->next"};
+    const char *names[8] = {"extract+local-max", "dpp-max+index", "cand-row+divide+publish", "barrier", "key+prn-read", "eliminate", "fixup+labels", "->next"};
     double sum[8] = {0};
     for (int r = 0; r < 16; ++r)
         for (int s = 0; s < 8; ++s) {
