@@ -93,7 +93,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct BlockedWs {
     float *m0, *m1;   // the two working copies, np x ld each
     float *pt, *gt;   // compact transposed panels, kMaxW x np each: panel kernel input / output
-    int *submap, *rowsrc, *orig, *invp;
+    int *submap, *rowsrc[2], *orig, *invp;  // rowsrc is double-buffered across blocks (look-ahead)
     size_t mstride;   // floats per matrix in m0/m1
     size_t tstride;   // floats per matrix in pt/gt
 };
@@ -114,7 +114,9 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
     off += tbytes * batch;
     if (o) o->submap = (int *)(c + off);
     off += ibytes;
-    if (o) o->rowsrc = (int *)(c + off);
+    if (o) o->rowsrc[0] = (int *)(c + off);
+    off += ibytes;
+    if (o) o->rowsrc[1] = (int *)(c + off);
     off += ibytes;
     if (o) o->orig = (int *)(c + off);
     off += ibytes;
@@ -517,7 +519,8 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
                                                               int np, int ld, size_t mstride, int c0, int kdim,
                                                               int col_lo, const int *__restrict__ map_all,
                                                               int copy_panel, float *__restrict__ pt_out_all,
-                                                              size_t tstride, int pt_col, int pt_w)
+                                                              size_t tstride, int pt_col, int pt_w, int skip_lo,
+                                                              int skip_hi)
 {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -541,6 +544,7 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     const int *map = map_all + (size_t)b * np;
     float *pt_out = pt_out_all + (size_t)b * tstride;
 
+    if (col0 >= skip_lo && col0 < skip_hi) return;  // these columns belong to the other half of a split update
     if (!COMPACT_G && col0 >= c0 && col0 + BN <= c0 + kdim) {
         // tile lies inside the panel: those columns are G itself
         if (copy_panel) {
@@ -682,21 +686,20 @@ __global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *
 
 #ifndef MI32_STAMPS
 template <int NT, int RPT, int W>
-static void launch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int first, int batch, int *d_status,
-                         hipStream_t stream)
+static void launch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int first, int *rowsrc, int batch,
+                         int *d_status, hipStream_t stream)
 {
     hipLaunchKernelGGL((gj_panel_kernel<NT, RPT, W>), dim3(batch), dim3(NT), 2 * RPT * NT * sizeof(int), stream, ws.pt,
-                       ws.gt, p.np, p.n,
-                       ws.tstride, c0, ws.submap, ws.rowsrc, ws.orig, first, d_status);
+                       ws.gt, p.np, p.n, ws.tstride, c0, ws.submap, rowsrc, ws.orig, first, d_status);
 }
 
-static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int first, int batch, int *d_status,
-                           hipStream_t stream)
+static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int first, int *rowsrc, int batch,
+                           int *d_status, hipStream_t stream)
 {
-#define MI32_PANEL_CASE(T, R, WW)                                            \
-    if (p.nthreads_panel == T && p.rpt == R && p.w == WW) {                  \
-        launch_panel<T, R, WW>(p, ws, c0, first, batch, d_status, stream);   \
-        return true;                                                         \
+#define MI32_PANEL_CASE(T, R, WW)                                                    \
+    if (p.nthreads_panel == T && p.rpt == R && p.w == WW) {                          \
+        launch_panel<T, R, WW>(p, ws, c0, first, rowsrc, batch, d_status, stream);   \
+        return true;                                                                 \
     }
     MI32_PANEL_CASE(512, 1, 16) MI32_PANEL_CASE(512, 2, 16) MI32_PANEL_CASE(512, 4, 16) MI32_PANEL_CASE(512, 8, 16)
     MI32_PANEL_CASE(512, 1, 8) MI32_PANEL_CASE(512, 2, 8) MI32_PANEL_CASE(512, 4, 8) MI32_PANEL_CASE(512, 8, 8)
@@ -719,33 +722,48 @@ static void launch_inner_update(const BlockedPlan &p, const BlockedWs &ws, const
     const int pt_col = (next < C0 + kb) ? next : -(1 << 30);
 #define MI32_INNER(BKV)                                                                                             \
     hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, BKV, true>), grid, dim3(256), 0, stream, x, y, ws.gt,          \
-                       ws.tstride, p.np, p.ld, ws.mstride, c0, BKV, C0, ws.submap, 0, ws.pt, ws.tstride, pt_col, p.w)
+                       ws.tstride, p.np, p.ld, ws.mstride, c0, BKV, C0, ws.submap, 0, ws.pt, ws.tstride, pt_col, p.w, 0, 0)
     if (p.w == 16) MI32_INNER(16);
     else if (p.w == 8) MI32_INNER(8);
     else MI32_INNER(4);
 #undef MI32_INNER
 }
 
+// Look-ahead: the rank-bw update of block b is split into (A) the columns of block b+1, which the next
+// panel phase needs at once, and (B) all other columns.  (A) stays on the main stream; (B) runs on a
+// second stream and overlaps with block b+1's panel phase, which is latency bound on a few CUs.  The
+// next rank-bw update (and the final un-permutation) wait for (B) through an event.
 hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *wsp,
-                          hipStream_t stream, Profiler *prof)
+                          const BlockedExec &ex)
 {
     BlockedWs ws;
     blocked_carve(p, batch, wsp, &ws);
     const int np = p.np;
+    hipStream_t stream = ex.stream;
+    Profiler *prof = ex.prof;
+    const bool lookahead = ex.aux != nullptr && ex.n_events >= 4;
+    hipError_t e;
     {
         ProfScope ps(prof, KC_INIT, stream);
         hipLaunchKernelGGL(blocked_init_kernel, dim3((np + 255) / 256, (np + 15) / 16, batch), dim3(256), 0, stream,
                            d_a, p.n, np, p.ld, ws.mstride, ws.m0, ws.pt, ws.tstride, p.w, ws.orig, d_status);
     }
+    if (lookahead) {  // whatever still runs on the second stream from an earlier call shares this workspace
+        if ((e = hipEventRecord(ex.events[0], ex.aux)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, ex.events[0], 0)) != hipSuccess) return e;
+    }
     float *cur = ws.m0, *oth = ws.m1;
-    for (int C0 = 0; C0 < np; C0 += p.bw) {
+    bool pending_b = false;  // a (B) half is in flight on the second stream
+    int blk = 0, ev = 0;
+    for (int C0 = 0; C0 < np; C0 += p.bw, ++blk) {
         const int kb = (C0 + p.bw <= np) ? p.bw : np - C0;
+        int *rowsrc = ws.rowsrc[blk & 1];
         float *x = cur, *y = oth;  // the block's panel columns alternate between the two copies
         for (int s = 0; s * p.w < kb; ++s) {
             const int c0 = C0 + s * p.w;
             {
                 ProfScope ps(prof, KC_PANEL, stream);
-                if (!dispatch_panel(p, ws, c0, s == 0, batch, d_status, stream)) return hipErrorInvalidValue;
+                if (!dispatch_panel(p, ws, c0, s == 0, rowsrc, batch, d_status, stream)) return hipErrorInvalidValue;
             }
             {
                 ProfScope ps(prof, KC_UPDATE_IN, stream);
@@ -755,17 +773,49 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
         }
         // x now holds the block's G; every other column is still valid in `cur` only
         if (kb < np) {
-            const dim3 grid(np / 128, np / 128, batch);
-            const int next = C0 + kb;  // first sub-panel of the next block: export it into pt
-            const int pt_col = (next < np) ? next : -(1 << 30);
-            ProfScope ps(prof, KC_UPDATE_OUT, stream);
-            hipLaunchKernelGGL((gj_rank_update_kernel<128, 128, 32, false>), grid, dim3(256), 0, stream, cur, oth, x,
-                               ws.mstride, np, p.ld, ws.mstride, C0, kb, 0, ws.rowsrc, (x != oth) ? 1 : 0, ws.pt,
-                               ws.tstride, pt_col, p.w);
+            const int next = C0 + kb;  // first column of the next block
+            const bool has_next = next < np;
+            const int kb_next = has_next ? ((next + p.bw <= np) ? p.bw : np - next) : 0;
+            const int pt_col = has_next ? next : -(1 << 30);
+            const int copy = (x != oth) ? 1 : 0;
+            if (pending_b) {  // this update reads all of `cur` and overwrites `oth`: the previous (B) must be done
+                if ((e = hipStreamWaitEvent(stream, ex.events[ev], 0)) != hipSuccess) return e;
+                pending_b = false;
+            }
+            if (lookahead && has_next) {
+                {   // (A): the next block's columns, on the main stream; exports the next sub-panel
+                    ProfScope ps(prof, KC_UPDATE_OUT, stream);
+                    // small tiles: only kb_next columns, so 64x64 gives 4x the workgroups of 128x128
+                    hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 32, false>), dim3(kb_next / 64, np / 64, batch),
+                                       dim3(256), 0, stream, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, next,
+                                       rowsrc, copy, ws.pt, ws.tstride, pt_col, p.w, 0, 0);
+                }
+                // (B): everything else, on the second stream, after this block's panel phase
+                ev = (ev + 1) % (ex.n_events / 2);
+                hipEvent_t e_panel = ex.events[ex.n_events / 2 + ev];
+                if ((e = hipEventRecord(e_panel, stream)) != hipSuccess) return e;
+                if ((e = hipStreamWaitEvent(ex.aux, e_panel, 0)) != hipSuccess) return e;
+                {
+                    ProfScope ps(prof, KC_UPDATE_OUT, ex.aux);
+                    hipLaunchKernelGGL((gj_rank_update_kernel<128, 128, 32, false>), dim3(np / 128, np / 128, batch),
+                                       dim3(256), 0, ex.aux, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, 0,
+                                       rowsrc, copy, ws.pt, ws.tstride, -(1 << 30), p.w, next, next + kb_next);
+                }
+                if ((e = hipEventRecord(ex.events[ev], ex.aux)) != hipSuccess) return e;
+                pending_b = true;
+            } else {
+                ProfScope ps(prof, KC_UPDATE_OUT, stream);
+                hipLaunchKernelGGL((gj_rank_update_kernel<128, 128, 32, false>), dim3(np / 128, np / 128, batch),
+                                   dim3(256), 0, stream, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, 0,
+                                   rowsrc, copy, ws.pt, ws.tstride, pt_col, p.w, 0, 0);
+            }
             float *t = cur; cur = oth; oth = t;
         } else {
             cur = x;  // single block: the panel is the whole matrix
         }
+    }
+    if (pending_b) {
+        if ((e = hipStreamWaitEvent(stream, ex.events[ev], 0)) != hipSuccess) return e;
     }
     ProfScope ps(prof, KC_FINISH, stream);
     // over ALL np entries: orig is a permutation of [0, np), so every invp[j] is defined and in range

@@ -66,6 +66,8 @@ struct mi32_context {
     int device = 0;
     EventProfiler *prof = nullptr;
     hipEvent_t switch_event = nullptr;
+    hipStream_t aux_stream = nullptr;   // look-ahead half of the rank-bw updates
+    hipEvent_t la_events[8] = {};
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     void *ws = nullptr;
@@ -127,6 +129,7 @@ static int ensure_ws(mi32_context *h, size_t bytes)
     if (bytes <= h->ws_bytes) return MI32_OK;
     if (h->ws) {
         MI32_HIP(hipStreamSynchronize(h->stream));
+        if (h->aux_stream) MI32_HIP(hipStreamSynchronize(h->aux_stream));
         MI32_HIP(hipFree(h->ws));
         h->ws = nullptr;
         h->ws_bytes = 0;
@@ -162,6 +165,18 @@ int mi32_create(mi32_handle_t *out, int device)
     MI32_HIP(hipSetDevice(device));
     MI32_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
+    if (env_int("MI32_LOOKAHEAD", 0)) {
+        // Opt-in look-ahead (see blocked_invert): the half of each rank-bw update that is not on the
+        // critical path runs on a second, lowest-priority stream.  Measured on MI355X it is neutral
+        // (11.56 vs 11.55 ms at N=4096): the overlap happens, but that half's workgroups fill every
+        // CU's register file and the next panel / in-block kernels queue behind them; confining it
+        // with hipExtStreamCreateWithCUMask serialises the two queues altogether (17 ms).  Kept for a
+        // persistent, occupancy-limited variant of that kernel.
+        int prio_low = 0, prio_high = 0;
+        MI32_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        MI32_HIP(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_low));
+        for (auto &ev : h->la_events) MI32_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     *out = h;
     return MI32_OK;
 }
@@ -177,6 +192,12 @@ int mi32_destroy(mi32_handle_t h)
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->switch_event) (void)hipEventDestroy(h->switch_event);
+    if (h->aux_stream) {
+        (void)hipStreamSynchronize(h->aux_stream);
+        (void)hipStreamDestroy(h->aux_stream);
+    }
+    for (auto ev : h->la_events)
+        if (ev) (void)hipEventDestroy(ev);
     delete h->prof;
     delete h;
     return MI32_OK;
@@ -250,8 +271,15 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
     hipError_t e;
     if (algo == MI32_ALGO_SWEEP)
         e = sweep_invert(make_sweep_plan(n), d_a, d_inv, batch, d_status, h->ws, h->stream, h->prof);
-    else
-        e = blocked_invert(plan_blocked(h, n), d_a, d_inv, batch, d_status, h->ws, h->stream, h->prof);
+    else {
+        BlockedExec ex;
+        ex.stream = h->stream;
+        ex.aux = h->aux_stream;
+        ex.events = h->la_events;
+        ex.n_events = h->aux_stream ? 8 : 0;
+        ex.prof = h->prof;
+        e = blocked_invert(plan_blocked(h, n), d_a, d_inv, batch, d_status, h->ws, ex);
+    }
     if (e != hipSuccess) return fail(e, "kernel launch");
     return MI32_OK;
 }

@@ -89,8 +89,17 @@ size_t blocked_workspace_bytes(const BlockedPlan &p, int batch);
 // reported above, 256-byte aligned.
 hipError_t sweep_invert(const SweepPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *ws,
                         hipStream_t stream, Profiler *prof);
+// streams/events a blocked inversion is enqueued with: `aux` (may be null) carries the look-ahead half
+// of each rank-bw update; events[0 .. n/2) mark "second-stream work done", events[n/2 .. n) "panel phase done"
+struct BlockedExec {
+    hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;
+    hipEvent_t *events = nullptr;
+    int n_events = 0;
+    Profiler *prof = nullptr;
+};
 hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *ws,
-                          hipStream_t stream, Profiler *prof);
+                          const BlockedExec &ex);
 hipError_t residual_launch(const float *d_a, const float *d_x, int n, int batch, double *d_out, void *ws,
                            hipStream_t stream);
 size_t residual_workspace_bytes(int n, int batch);
