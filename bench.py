@@ -192,6 +192,13 @@ def main():
         inv.set_profiling(False)
         breakdown = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
                          "avg_us": (1e3 * v[0] / v[1]) if v[1] else None} for k, v in prof.items() if v[1]}
+        # the roofline object below is for the kernel that carries the algorithmic flops (the fp32-MFMA
+        # rank-bw update: 2 N^3 (1 - bw/N) of the 2 N^3).  For a SINGLE matrix the time-dominant kernel
+        # is the latency-bound panel kernel (one workgroup, one barrier per pivot step): no roofline
+        # applies to it; its share is reported here.
+        tot_ms = sum(v[0] for v in prof.values()) or 1.0
+        time_dominant = max(prof.items(), key=lambda kv: kv[1][0])
+        breakdown["_time_dominant"] = {"class": time_dominant[0], "share_of_kernel_time": time_dominant[1][0] / tot_ms}
         if algo_id == g.ALGO_BLOCKED:
             ms, cnt = prof["update_rank_bw"]
             plan_bw = args.block_width or 256
@@ -202,9 +209,15 @@ def main():
             flops = 2.0 * n * max(n - bw, 0) * bw * batch
             avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
             ach = flops / avg_s / 1e12 if cnt else None
-            roof = {"bound": "mfma", "kernel": "gj_rank_update_kernel<128,128,32>", "achieved": ach,
+            # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, x1024),
+            # collected offline with rocprofv3 --pmc (separate passes) on this exact config
+            traffic = None
+            pmc_path = os.path.join(ROOT, "profiles", "round1", "pmc_rank_bw_n4096.json")
+            if n == 4096 and batch == 1 and bw == 256 and os.path.exists(pmc_path):
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch_corrected")
+            roof = {"bound": "mfma", "kernel": "gj_rank_bw_update_kernel", "achieved": ach,
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
-                    "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt / args.steps,
+                    "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt / args.steps,
                     "algorithmic_flops_per_launch": flops,
                     "share_of_step_time": (ms / args.steps) / (1e3 * instrumented / args.steps)}
         else:

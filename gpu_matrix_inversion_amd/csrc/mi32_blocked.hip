@@ -48,6 +48,14 @@ namespace mi32 {
 
 typedef float float16v __attribute__((ext_vector_type(16)));
 
+// k-tile depth and waves/SIMD of the pipelined rank-bw update (tunable at build time)
+#ifndef MI32_BW_BK
+#define MI32_BW_BK 16
+#endif
+#ifndef MI32_BW_WPS
+#define MI32_BW_WPS 3
+#endif
+
 static constexpr int kMaxW = 16;  // widest sub-panel (columns kept in registers)
 
 // Panel-kernel geometry: NT threads hold np rows x w columns in registers, rpt rows each.
@@ -659,6 +667,148 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
         }
 }
 
+// ---- the rank-bw update, pipelined --------------------------------------------------
+// Same arithmetic as gj_rank_update_kernel<128,128,32,false> (one k-ascending MFMA chain per output
+// element, so results are bit-identical), restructured for the matrix pipe:
+//  * register-staged double buffering: the global loads of k-tile t+1 are issued before the 64 MFMAs of
+//    k-tile t and written to the other LDS buffer after them -> one barrier per k-tile instead of two,
+//    and the loads' latency hides under the MFMAs;
+//  * XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) cover a compact (T/2) x (T/4)
+//    sub-grid of tiles, so that XCD's 4 MiB L2 holds the A and B panels its tiles re-read.
+template <int BK, int WPS>
+__global__ __launch_bounds__(256, WPS) void gj_rank_bw_update_kernel(const float *__restrict__ src_all,
+                                                                   float *__restrict__ dst_all,
+                                                                   const float *__restrict__ g_all, size_t gstride,
+                                                                   int np, int ld, size_t mstride, int c0, int kdim,
+                                                                   const int *__restrict__ map_all, int copy_panel,
+                                                                   float *__restrict__ pt_out_all, size_t tstride,
+                                                                   int pt_col, int pt_w, int skip_lo, int skip_hi)
+{
+    constexpr int BM = 128, BN = 128;
+    constexpr int NQ = BK / 8;  // float4 per thread per operand tile
+    constexpr int LDA = BM + (BK == 32 ? 1 : 2), LDB = BN + 4;
+    __shared__ float s_a[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float s_b[2][BK * LDB];
+    __shared__ int s_map[BM];
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int T = np / BM;  // tiles per dimension
+    int rt, ct;
+    if ((T & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int tr = T / 2, tc = T / 4;  // sub-grid of one XCD: tr row tiles x tc column tiles
+        rt = (xcd >> 2) * tr + idx / tc;
+        ct = (xcd & 3) * tc + idx % tc;
+    } else {
+        rt = blockIdx.x / T;
+        ct = blockIdx.x % T;
+    }
+    const int row0 = rt * BM, col0 = ct * BN;
+    const float *src = src_all + (size_t)b * mstride;
+    float *dst = dst_all + (size_t)b * mstride;
+    const float *g = g_all + (size_t)b * gstride;
+    const int *map = map_all + (size_t)b * np;
+    float *pt_out = pt_out_all + (size_t)b * tstride;
+
+    if (col0 >= skip_lo && col0 < skip_hi) return;
+    if (col0 >= c0 && col0 + BN <= c0 + kdim) {  // tile inside the panel: those columns are G itself
+        if (copy_panel) {
+            for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+                const int rr = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+                *reinterpret_cast<float4 *>(dst + (size_t)(row0 + rr) * ld + col0 + c4) =
+                    *reinterpret_cast<const float4 *>(g + (size_t)(row0 + rr) * ld + col0 + c4);
+            }
+        }
+        return;
+    }
+
+    // staging: A tile 128 rows x BK k (float4 idx: row = idx / (BK/4), k4 = idx % (BK/4)),
+    //          B tile BK k x 128 columns (k = idx / 32, c4 = idx % 32); idx = tid + 256 q, q < BK/8
+    typedef float f4v __attribute__((ext_vector_type(4)));  // native vector: HIP's float4 struct in an array goes to scratch
+    f4v ra[NQ], rb[NQ];
+#define MI32_LOAD_TILES(KT)                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                               \
+        const int idx = tid + q * 256;                                                                             \
+        ra[q] = *reinterpret_cast<const f4v *>(g + (size_t)(row0 + idx / (BK / 4)) * ld + c0 + (KT) +              \
+                                               (idx % (BK / 4)) * 4);                                              \
+        rb[q] = *reinterpret_cast<const f4v *>(src + (size_t)map[c0 + (KT) + (idx >> 5)] * ld + col0 +             \
+                                                  (idx & 31) * 4);                                                 \
+    }
+#define MI32_STORE_TILES(BUF)                                                                  \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                           \
+        const int idx = tid + q * 256;                                                         \
+        float *pa = &s_a[BUF][((idx % (BK / 4)) * 4) * LDA + idx / (BK / 4)];                  \
+        pa[0] = ra[q][0]; pa[LDA] = ra[q][1]; pa[2 * LDA] = ra[q][2]; pa[3 * LDA] = ra[q][3];  \
+        *reinterpret_cast<f4v *>(&s_b[BUF][(idx >> 5) * LDB + (idx & 31) * 4]) = rb[q];        \
+    }
+
+    MI32_LOAD_TILES(0)
+    if (tid < BM) s_map[tid] = map[row0 + tid];
+    __syncthreads();
+
+    // accumulators start from the (row-mapped) old values; rows of the block start from 0
+    float16v acc[2][2];
+    const int lcol = lane & 31;
+    const int lhalf = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = col0 + wc * 64 + tn * 32 + lcol;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                const int grow = row0 + lr;
+                const bool in_block = (grow >= c0 && grow < c0 + kdim);
+                acc[tm][tn][reg] = in_block ? 0.0f : src[(size_t)s_map[lr] * ld + col];
+            }
+        }
+    MI32_STORE_TILES(0)
+    __syncthreads();
+
+    const int nk = kdim / BK;
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        const int ktn = (t + 1 < nk) ? (t + 1) * BK : t * BK;  // last iteration: harmless re-load, keeps the loop branch-free
+        MI32_LOAD_TILES(ktn)
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) af[tm] = s_a[buf][(kk + lhalf) * LDA + wr * 64 + tm * 32 + lcol];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) bf[tn] = s_b[buf][(kk + lhalf) * LDB + wc * 64 + tn * 32 + lcol];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+        }
+        MI32_STORE_TILES(buf ^ 1)
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = col0 + wc * 64 + tn * 32 + lcol;
+            const bool exp = (col >= pt_col && col < pt_col + pt_w);  // next sub-panel's column
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int grow = row0 + wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                dst[(size_t)grow * ld + col] = acc[tm][tn][reg];
+                if (exp) pt_out[(size_t)(col - pt_col) * np + grow] = acc[tm][tn][reg];
+            }
+        }
+#undef MI32_LOAD_TILES
+#undef MI32_STORE_TILES
+}
+
 // ---- getInvertedMatrix counterpart: undo the column permutation ----------------
 __global__ void invert_perm_ld_kernel(const int *__restrict__ orig, int *__restrict__ invp, int n, int istride)
 {
@@ -797,17 +947,17 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 if ((e = hipStreamWaitEvent(ex.aux, e_panel, 0)) != hipSuccess) return e;
                 {
                     ProfScope ps(prof, KC_UPDATE_OUT, ex.aux);
-                    hipLaunchKernelGGL((gj_rank_update_kernel<128, 128, 32, false>), dim3(np / 128, np / 128, batch),
-                                       dim3(256), 0, ex.aux, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, 0,
-                                       rowsrc, copy, ws.pt, ws.tstride, -(1 << 30), p.w, next, next + kb_next);
+                    hipLaunchKernelGGL((gj_rank_bw_update_kernel<MI32_BW_BK, MI32_BW_WPS>), dim3((np / 128) * (np / 128), batch), dim3(256), 0,
+                                       ex.aux, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy,
+                                       ws.pt, ws.tstride, -(1 << 30), p.w, next, next + kb_next);
                 }
                 if ((e = hipEventRecord(ex.events[ev], ex.aux)) != hipSuccess) return e;
                 pending_b = true;
             } else {
                 ProfScope ps(prof, KC_UPDATE_OUT, stream);
-                hipLaunchKernelGGL((gj_rank_update_kernel<128, 128, 32, false>), dim3(np / 128, np / 128, batch),
-                                   dim3(256), 0, stream, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, 0,
-                                   rowsrc, copy, ws.pt, ws.tstride, pt_col, p.w, 0, 0);
+                hipLaunchKernelGGL((gj_rank_bw_update_kernel<MI32_BW_BK, MI32_BW_WPS>), dim3((np / 128) * (np / 128), batch), dim3(256), 0, stream,
+                                   cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt,
+                                   ws.tstride, pt_col, p.w, 0, 0);
             }
             float *t = cur; cur = oth; oth = t;
         } else {

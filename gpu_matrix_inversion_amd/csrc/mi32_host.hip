@@ -249,7 +249,7 @@ int mi32_resolve_algo(mi32_handle_t h, int n, int /*batch*/) { return resolve_al
 
 const char *mi32_dominant_kernel(int algo)
 {
-    return algo == MI32_ALGO_SWEEP ? "gj_sweep_step_kernel" : "gj_rank_update_kernel";
+    return algo == MI32_ALGO_SWEEP ? "gj_sweep_step_kernel" : "gj_rank_bw_update_kernel";
 }
 
 int mi32_reserve(mi32_handle_t h, int n, int batch)

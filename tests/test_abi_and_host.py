@@ -85,7 +85,7 @@ def test_workspace_sizes():
     # padding to a multiple of 128 in the blocked path
     assert lib.mi32_workspace_bytes(1000, 1, _lib.ALGO_BLOCKED) >= 2 * 1024 * 1024 * 4
     assert lib.mi32_dominant_kernel(_lib.ALGO_SWEEP) == b"gj_sweep_step_kernel"
-    assert lib.mi32_dominant_kernel(_lib.ALGO_BLOCKED) == b"gj_rank_update_kernel"
+    assert lib.mi32_dominant_kernel(_lib.ALGO_BLOCKED) == b"gj_rank_bw_update_kernel"
 
 
 @pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
