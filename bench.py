@@ -201,9 +201,7 @@ def main():
         breakdown["_time_dominant"] = {"class": time_dominant[0], "share_of_kernel_time": time_dominant[1][0] / tot_ms}
         if algo_id == g.ALGO_BLOCKED:
             ms, cnt = prof["update_rank_bw"]
-            plan_bw = args.block_width or 256
-            np_pad = (n + 127) // 128 * 128
-            bw = min((plan_bw + 127) // 128 * 128, 512, np_pad)
+            _, bw = inv.resolved_blocking(n, batch)
             # ALGORITHMIC flops of one rank-bw update launch: 2 * N * (N - bw) * bw per matrix
             # (sum over the N/bw launches = 2 N^3 (1 - bw/N): the block's own columns are done in-panel)
             flops = 2.0 * n * max(n - bw, 0) * bw * batch
@@ -251,7 +249,7 @@ def main():
             "workload": ("C1 (BASELINE configs[1]): single 4096x4096 fp32 inversion per GPU per step"
                          if (n == 4096 and batch == 1) else
                          f"batch of {batch} independent {n}x{n} fp32 matrices per GPU per step"),
-            "n": n, "batch_per_gpu": batch, "algo": algo_name, "distribution": "D_gate (row-permuted U(-1,1)+sqrt(N) I)",
+            "n": n, "batch_per_gpu": batch, "algo": algo_name, "blocking": list(inv.resolved_blocking(n, batch)), "distribution": "D_gate (row-permuted U(-1,1)+sqrt(N) I)",
             "parallelism": "independent matrices sharded over ranks, no data-path collective",
             "vs_baseline_denominator": "0.342 matrices/s: reference kernel loop, N=4096, RX 5700 (BASELINE.md)",
         },

@@ -43,6 +43,7 @@ C_ABI_SYMBOLS = (
     "mi32_get_profile",
     "mi32_last_timing",
     "mi32_resolve_algo",
+    "mi32_resolve_blocking",
     "mi32_dominant_kernel",
     "mi32_last_error",
     "mi32_version",
@@ -119,6 +120,8 @@ def load() -> ctypes.CDLL:
     lib.mi32_last_timing.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     lib.mi32_resolve_algo.restype = ctypes.c_int
     lib.mi32_resolve_algo.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.mi32_resolve_blocking.restype = ctypes.c_int
+    lib.mi32_resolve_blocking.argtypes = [vp, ctypes.c_int, ctypes.c_int, ip, ip]
     lib.mi32_dominant_kernel.restype = ctypes.c_char_p
     lib.mi32_dominant_kernel.argtypes = [ctypes.c_int]
     lib.mi32_last_error.restype = ctypes.c_char_p

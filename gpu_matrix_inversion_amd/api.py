@@ -134,6 +134,13 @@ class Inverter:
     def resolved_algo(self, n: int, batch: int = 1) -> int:
         return self._lib.mi32_resolve_algo(self._h, int(n), int(batch))
 
+    def resolved_blocking(self, n: int, batch: int = 1):
+        """(sub-panel width, outer block width) the blocked path uses for this shape."""
+        w, bw = ctypes.c_int(), ctypes.c_int()
+        _lib.check(self._lib.mi32_resolve_blocking(self._h, int(n), int(batch), ctypes.byref(w), ctypes.byref(bw)),
+                   "mi32_resolve_blocking")
+        return w.value, bw.value
+
     def dominant_kernel(self, n: int, batch: int = 1) -> str:
         return self._lib.mi32_dominant_kernel(self.resolved_algo(n, batch)).decode()
 

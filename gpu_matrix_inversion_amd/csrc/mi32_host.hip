@@ -106,20 +106,28 @@ static int resolve_algo(const mi32_context *h, int n)
 {
     int algo = h ? h->algo : MI32_ALGO_AUTO;
     if (algo == MI32_ALGO_AUTO) algo = env_int("MI32_ALGO", MI32_ALGO_AUTO);
-    if (algo != MI32_ALGO_SWEEP && algo != MI32_ALGO_BLOCKED) algo = (n >= 96) ? MI32_ALGO_BLOCKED : MI32_ALGO_SWEEP;
+    if (algo != MI32_ALGO_SWEEP && algo != MI32_ALGO_BLOCKED) algo = (n >= 32) ? MI32_ALGO_BLOCKED : MI32_ALGO_SWEEP;  // measured cross-over on MI355X
     if (algo == MI32_ALGO_BLOCKED && !blocked_supported(n)) algo = MI32_ALGO_SWEEP;  // panel would not fit in registers
     return algo;
 }
-static BlockedPlan plan_blocked(const mi32_context *h, int n)
+static BlockedPlan plan_blocked(const mi32_context *h, int n, int batch)
 {
     int w = h && h->panel_w ? h->panel_w : env_int("MI32_PANEL_W", 0);
     int bw = h && h->block_w ? h->block_w : env_int("MI32_BLOCK_W", 0);
+    if (bw == 0) {
+        // A single matrix is bound by the pivot chain and bw = 256 gives the rank-bw update its best
+        // arithmetic intensity.  A batch that fills the GPU is bound by the HBM traffic of the in-block
+        // updates (np x bw re-written per sub-panel): bw = 128 halves it (measured 64 x 2048^2:
+        // 23.0 ms vs 24.7 ms; single 4096^2: 11.4 ms vs 11.2 ms).
+        const double elems = (double)batch * (double)n * (double)n;
+        bw = (batch >= 8 && elems >= 64.0 * 1024.0 * 1024.0) ? 128 : 256;
+    }
     return make_blocked_plan(n, w, bw);
 }
 static size_t ws_bytes_for(const mi32_context *h, int n, int batch, int algo)
 {
     size_t a = (algo == MI32_ALGO_SWEEP) ? sweep_workspace_bytes(make_sweep_plan(n), batch)
-                                         : blocked_workspace_bytes(plan_blocked(h, n), batch);
+                                         : blocked_workspace_bytes(plan_blocked(h, n, batch), batch);
     size_t r = residual_workspace_bytes(n, batch);
     return a > r ? a : r;
 }
@@ -247,6 +255,15 @@ size_t mi32_workspace_bytes(int n, int batch, int algo)
 
 int mi32_resolve_algo(mi32_handle_t h, int n, int /*batch*/) { return resolve_algo(h, n); }
 
+int mi32_resolve_blocking(mi32_handle_t h, int n, int batch, int *panel_width, int *block_width)
+{
+    if (n <= 0 || batch <= 0) return MI32_BAD_SHAPE;
+    const BlockedPlan p = plan_blocked(h, n, batch);
+    if (panel_width) *panel_width = p.w;
+    if (block_width) *block_width = p.bw;
+    return MI32_OK;
+}
+
 const char *mi32_dominant_kernel(int algo)
 {
     return algo == MI32_ALGO_SWEEP ? "gj_sweep_step_kernel" : "gj_rank_bw_update_kernel";
@@ -278,7 +295,7 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
         ex.events = h->la_events;
         ex.n_events = h->aux_stream ? 8 : 0;
         ex.prof = h->prof;
-        e = blocked_invert(plan_blocked(h, n), d_a, d_inv, batch, d_status, h->ws, ex);
+        e = blocked_invert(plan_blocked(h, n, batch), d_a, d_inv, batch, d_status, h->ws, ex);
     }
     if (e != hipSuccess) return fail(e, "kernel launch");
     return MI32_OK;

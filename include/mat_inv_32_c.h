@@ -106,6 +106,8 @@ int mi32_get_profile(mi32_handle_t h, double *ms_per_class, long long *launches_
 int mi32_last_timing(double *total_seconds, double *compute_seconds);
 /* which algorithm a call of this shape would use after AUTO resolution */
 int mi32_resolve_algo(mi32_handle_t h, int n, int batch);
+/* sub-panel and outer block width the blocked path would use for this shape */
+int mi32_resolve_blocking(mi32_handle_t h, int n, int batch, int *panel_width, int *block_width);
 /* name of the dominant device kernel of that algorithm (for rocprof filtering) */
 const char *mi32_dominant_kernel(int algo);
 /* thread-local description of the last MI32_RUNTIME_ERROR */

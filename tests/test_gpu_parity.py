@@ -270,6 +270,17 @@ def test_c1_single_4096_sweep_and_blocked_agree(inv_sweep, inv_blocked):
     assert rel < 1e-5, rel
 
 
+def test_blocked_4200_w8_instance_bit_identical_to_mirror(oracle, inv_blocked):
+    """N = 4200 pads to 4224 rows: 1024 threads x 8 rows, which only fits W = 8 columns in registers."""
+    n = 4200
+    a = gate_matrix(n, 40_000)
+    w, bw = inv_blocked.resolved_blocking(n, 1)
+    assert (w, bw) == (8, 256)
+    got, st = run(inv_blocked, a)
+    want = oracle.matrix_inv_32_blocked2(a, n, w, bw)
+    assert st[0] == 0 and np.array_equal(got.reshape(-1), want)
+
+
 def test_sweep_2048_bit_identical_to_oracle(oracle, inv_sweep):
     n = 2048
     a = gate_matrix(n, 20_000)
