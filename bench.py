@@ -17,6 +17,8 @@ Extra objects on the same line:
                    durations come from HIP events recorded on the launch stream (inside the
                    library, mi32_set_profiling) over a second, instrumented pass of the same K
                    steps, so the un-instrumented pass that yields `value` is not perturbed.
+                   (That pass runs with the look-ahead split off, so that every rank-bw update
+                   is one full-size launch of the kernel the roofline is quoted for.)
   cpu_baseline  -- numpy.linalg.inv (the reference's CPU path, matrix_inv_numpy.py:44, through
                    our just_inv-shaped harness) on the same fp32 input on this box's host cores.
 """
@@ -180,6 +182,7 @@ def main():
     roof = None
     breakdown = None
     if not args.no_profile_pass:
+        inv.set_lookahead(False)  # one clean full-size launch of the rank-bw kernel per block
         inv.set_profiling(True)
         inv.get_profile()
         torch.cuda.synchronize()
@@ -190,6 +193,7 @@ def main():
         instrumented = time.perf_counter() - tp0
         prof = inv.get_profile()
         inv.set_profiling(False)
+        inv.set_lookahead(True)
         breakdown = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
                          "avg_us": (1e3 * v[0] / v[1]) if v[1] else None} for k, v in prof.items() if v[1]}
         # the roofline object below is for the kernel that carries the algorithmic flops (the fp32-MFMA

@@ -35,6 +35,7 @@ C_ABI_SYMBOLS = (
     "mi32_set_stream",
     "mi32_set_algo",
     "mi32_set_blocking",
+    "mi32_set_lookahead",
     "mi32_workspace_bytes",
     "mi32_reserve",
     "mi32_inv_device",
@@ -104,6 +105,8 @@ def load() -> ctypes.CDLL:
     lib.mi32_set_algo.argtypes = [vp, ctypes.c_int]
     lib.mi32_set_blocking.restype = ctypes.c_int
     lib.mi32_set_blocking.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.mi32_set_lookahead.restype = ctypes.c_int
+    lib.mi32_set_lookahead.argtypes = [vp, ctypes.c_int]
     lib.mi32_workspace_bytes.restype = ctypes.c_size_t
     lib.mi32_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.mi32_reserve.restype = ctypes.c_int

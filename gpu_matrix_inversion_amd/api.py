@@ -173,6 +173,9 @@ class Inverter:
                    "mi32_inv_device")
         return (out[0] if squeeze else out), status
 
+    def set_lookahead(self, enable: bool):
+        _lib.check(self._lib.mi32_set_lookahead(self._h, 1 if enable else 0), "mi32_set_lookahead")
+
     def set_profiling(self, enable: bool):
         _lib.check(self._lib.mi32_set_profiling(self._h, 1 if enable else 0), "mi32_set_profiling")
 

@@ -291,24 +291,30 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], 
     for (int k = 0; k < RPT; ++k) col[k] = a[k][0];  // the pivot column is always register 0
     int own_lane = -1, own_k = 0;
     if (wave_active) {
-        unsigned m[RPT], id[RPT];
+        // candidate key of register row k: bits of |a| if the row is a valid candidate, else 0.  It is
+        // recomputed in the second pass rather than kept: 2*RPT fewer live registers, which is what
+        // lets the RPT = 16 instance (N = 16384) fit the 128-VGPR budget of 1024 threads.
+        auto cand_key = [&](int k, bool &ok) -> unsigned {
+            const float v = __builtin_fabsf(col[k]);
+            ok = ((unsigned)(pos[k] - slot) < span) && (v == v);
+            return ok ? __float_as_uint(v) : 0u;
+        };
+        unsigned bm = 0u;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const float v = __builtin_fabsf(col[k]);
-            const bool ok = ((unsigned)(pos[k] - slot) < span) && (v == v);
-            m[k] = ok ? __float_as_uint(v) : 0u;
-            id[k] = ok ? (unsigned)pos[k] : 0x7fffffffu;
+            bool ok;
+            const unsigned mk = cand_key(k, ok);
+            bm = mk > bm ? mk : bm;
         }
-        unsigned bm = m[0];
-#pragma unroll
-        for (int k = 1; k < RPT; ++k) bm = m[k] > bm ? m[k] : bm;
         MI32_STAMP(r, 1);
         const unsigned wm = wave_max_u32(bm);
         unsigned bi = 0x7fffffffu;
         int kb = 0;  // which of this lane's rows is its candidate
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const unsigned c = (m[k] == wm) ? id[k] : 0x7fffffffu;
+            bool ok;
+            const unsigned mk = cand_key(k, ok);
+            const unsigned c = (ok && mk == wm) ? (unsigned)pos[k] : 0x7fffffffu;
             const bool take = c < bi;
             bi = take ? c : bi;
             kb = take ? k : kb;
@@ -675,38 +681,22 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
 //    and the loads' latency hides under the MFMAs;
 //  * XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) cover a compact (T/2) x (T/4)
 //    sub-grid of tiles, so that XCD's 4 MiB L2 holds the A and B panels its tiles re-read.
-template <int BK, int WPS>
-__global__ __launch_bounds__(256, WPS) void gj_rank_bw_update_kernel(const float *__restrict__ src_all,
-                                                                   float *__restrict__ dst_all,
-                                                                   const float *__restrict__ g_all, size_t gstride,
-                                                                   int np, int ld, size_t mstride, int c0, int kdim,
-                                                                   const int *__restrict__ map_all, int copy_panel,
-                                                                   float *__restrict__ pt_out_all, size_t tstride,
-                                                                   int pt_col, int pt_w, int skip_lo, int skip_hi)
+template <int BK>
+__device__ __forceinline__ void rank_bw_tile(const float *__restrict__ src_all, float *__restrict__ dst_all,
+                                             const float *__restrict__ g_all, size_t gstride, int np, int ld,
+                                             size_t mstride, int c0, int kdim, const int *__restrict__ map_all,
+                                             int copy_panel, float *__restrict__ pt_out_all, size_t tstride,
+                                             int pt_col, int pt_w, int skip_lo, int skip_hi, int b, int rt, int ct,
+                                             float (&s_a)[2][BK * (128 + (BK == 32 ? 1 : 2))],
+                                             float (&s_b)[2][BK * (128 + 4)], int (&s_map)[128])
 {
     constexpr int BM = 128, BN = 128;
     constexpr int NQ = BK / 8;  // float4 per thread per operand tile
     constexpr int LDA = BM + (BK == 32 ? 1 : 2), LDB = BN + 4;
-    __shared__ float s_a[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float s_b[2][BK * LDB];
-    __shared__ int s_map[BM];
-
-    const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int T = np / BM;  // tiles per dimension
-    int rt, ct;
-    if ((T & 7) == 0) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int tr = T / 2, tc = T / 4;  // sub-grid of one XCD: tr row tiles x tc column tiles
-        rt = (xcd >> 2) * tr + idx / tc;
-        ct = (xcd & 3) * tc + idx % tc;
-    } else {
-        rt = blockIdx.x / T;
-        ct = blockIdx.x % T;
-    }
     const int row0 = rt * BM, col0 = ct * BN;
     const float *src = src_all + (size_t)b * mstride;
     float *dst = dst_all + (size_t)b * mstride;
@@ -809,6 +799,63 @@ __global__ __launch_bounds__(256, WPS) void gj_rank_bw_update_kernel(const float
 #undef MI32_STORE_TILES
 }
 
+// XCD-aware tile order: workgroups that share an XCD (linear id % 8) cover a compact (T/2) x (T/4)
+// sub-grid of tiles, so that XCD's 4 MiB L2 holds the A and B panels its tiles re-read.
+__device__ __forceinline__ void rank_bw_tile_of(int id, int T, int &rt, int &ct)
+{
+    if ((T & 7) == 0) {
+        const int xcd = id & 7, idx = id >> 3;
+        const int tr = T / 2, tc = T / 4;
+        rt = (xcd >> 2) * tr + idx / tc;
+        ct = (xcd & 3) * tc + idx % tc;
+    } else {
+        rt = id / T;
+        ct = id % T;
+    }
+}
+
+template <int BK, int WPS>
+__global__ __launch_bounds__(256, WPS) void gj_rank_bw_update_kernel(const float *__restrict__ src_all,
+                                                                     float *__restrict__ dst_all,
+                                                                     const float *__restrict__ g_all, size_t gstride,
+                                                                     int np, int ld, size_t mstride, int c0, int kdim,
+                                                                     const int *__restrict__ map_all, int copy_panel,
+                                                                     float *__restrict__ pt_out_all, size_t tstride,
+                                                                     int pt_col, int pt_w, int skip_lo, int skip_hi)
+{
+    __shared__ float s_a[2][BK * (128 + (BK == 32 ? 1 : 2))];
+    __shared__ __attribute__((aligned(16))) float s_b[2][BK * (128 + 4)];
+    __shared__ int s_map[128];
+    int rt, ct;
+    rank_bw_tile_of(blockIdx.x, np / 128, rt, ct);
+    rank_bw_tile<BK>(src_all, dst_all, g_all, gstride, np, ld, mstride, c0, kdim, map_all, copy_panel, pt_out_all,
+                     tstride, pt_col, pt_w, skip_lo, skip_hi, blockIdx.y, rt, ct, s_a, s_b, s_map);
+}
+
+// Persistent, residency-limited flavour for the look-ahead half: gridDim.x workgroups walk all the tiles.
+// It is launched with enough dynamic LDS that only ONE workgroup fits on a CU and with fewer workgroups
+// than CUs, so a known number of CUs stays entirely free for the critical-path kernels of the main
+// stream (the panel kernel needs a whole CU); stream priorities cannot give that guarantee and a CU
+// mask serialises the queues.
+template <int BK>
+__global__ __launch_bounds__(256, 1) void gj_rank_bw_update_persistent_kernel(
+    const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
+    int np, int ld, size_t mstride, int c0, int kdim, const int *__restrict__ map_all, int copy_panel,
+    float *__restrict__ pt_out_all, size_t tstride, int pt_col, int pt_w, int skip_lo, int skip_hi)
+{
+    __shared__ float s_a[2][BK * (128 + (BK == 32 ? 1 : 2))];
+    __shared__ __attribute__((aligned(16))) float s_b[2][BK * (128 + 4)];
+    __shared__ int s_map[128];
+    const int T = np / 128;
+    for (int id = blockIdx.x; id < T * T; id += gridDim.x) {
+        int rt, ct;
+        rank_bw_tile_of(id, T, rt, ct);
+        rank_bw_tile<BK>(src_all, dst_all, g_all, gstride, np, ld, mstride, c0, kdim, map_all, copy_panel, pt_out_all,
+                         tstride, pt_col, pt_w, skip_lo, skip_hi, blockIdx.y, rt, ct, s_a, s_b, s_map);
+        __syncthreads();  // the next tile re-uses the LDS buffers
+    }
+}
+
 // ---- getInvertedMatrix counterpart: undo the column permutation ----------------
 __global__ void invert_perm_ld_kernel(const int *__restrict__ orig, int *__restrict__ invp, int n, int istride)
 {
@@ -891,7 +938,9 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     const int np = p.np;
     hipStream_t stream = ex.stream;
     Profiler *prof = ex.prof;
-    const bool lookahead = ex.aux != nullptr && ex.n_events >= 4;
+    // look-ahead pays when the GPU is otherwise idle during the panel phase: a single large matrix
+    // (measured: 8192^2 51 -> 45 ms, 16384^2 399 -> 330 ms, 4096^2 11.2 -> 11.0 ms, 2048^2 4.2 -> 4.4 ms)
+    const bool lookahead = ex.aux != nullptr && ex.n_events >= 4 && ex.aux_workgroups > 0 && batch == 1 && np >= 4096;
     hipError_t e;
     {
         ProfScope ps(prof, KC_INIT, stream);
@@ -947,9 +996,18 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 if ((e = hipStreamWaitEvent(ex.aux, e_panel, 0)) != hipSuccess) return e;
                 {
                     ProfScope ps(prof, KC_UPDATE_OUT, ex.aux);
-                    hipLaunchKernelGGL((gj_rank_bw_update_kernel<MI32_BW_BK, MI32_BW_WPS>), dim3((np / 128) * (np / 128), batch), dim3(256), 0,
-                                       ex.aux, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy,
-                                       ws.pt, ws.tstride, -(1 << 30), p.w, next, next + kb_next);
+                    // persistent flavour: aux_workgroups (< number of CUs) workgroups, padded with dynamic LDS
+                    // so that one CU holds at most one of them -> the remaining CUs stay free for the main stream
+                    constexpr int kPadLds = 48 * 1024;
+                    static bool attr_set = false;
+                    if (!attr_set) {
+                        (void)hipFuncSetAttribute((const void *)gj_rank_bw_update_persistent_kernel<MI32_BW_BK>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kPadLds);
+                        attr_set = true;
+                    }
+                    hipLaunchKernelGGL((gj_rank_bw_update_persistent_kernel<MI32_BW_BK>), dim3(ex.aux_workgroups, batch),
+                                       dim3(256), kPadLds, ex.aux, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb,
+                                       rowsrc, copy, ws.pt, ws.tstride, -(1 << 30), p.w, next, next + kb_next);
                 }
                 if ((e = hipEventRecord(ex.events[ev], ex.aux)) != hipSuccess) return e;
                 pending_b = true;

@@ -68,6 +68,8 @@ struct mi32_context {
     hipEvent_t switch_event = nullptr;
     hipStream_t aux_stream = nullptr;   // look-ahead half of the rank-bw updates
     hipEvent_t la_events[8] = {};
+    int aux_workgroups = 0;
+    bool lookahead = true;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     void *ws = nullptr;
@@ -173,13 +175,19 @@ int mi32_create(mi32_handle_t *out, int device)
     MI32_HIP(hipSetDevice(device));
     MI32_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    if (env_int("MI32_LOOKAHEAD", 0)) {
-        // Opt-in look-ahead (see blocked_invert): the half of each rank-bw update that is not on the
-        // critical path runs on a second, lowest-priority stream.  Measured on MI355X it is neutral
-        // (11.56 vs 11.55 ms at N=4096): the overlap happens, but that half's workgroups fill every
-        // CU's register file and the next panel / in-block kernels queue behind them; confining it
-        // with hipExtStreamCreateWithCUMask serialises the two queues altogether (17 ms).  Kept for a
-        // persistent, occupancy-limited variant of that kernel.
+    if (env_int("MI32_LOOKAHEAD", 1)) {
+        // Look-ahead (see blocked_invert): the half of each rank-bw update that is not on the critical
+        // path runs on a second stream as a persistent kernel with one workgroup per CU on all but
+        // MI32_RESERVED_CUS compute units, which stay free for the panel / in-block kernels.
+        // (Tried and rejected on MI355X: a plain second stream -- its workgroups fill every CU's register
+        // file and the critical-path kernels queue behind them; hipExtStreamCreateWithCUMask -- it
+        // serialises the two queues, 17 ms instead of 11.5.)
+        hipDeviceProp_t prop;
+        MI32_HIP(hipGetDeviceProperties(&prop, device));
+        int reserve = env_int("MI32_RESERVED_CUS", 32);
+        if (reserve < 1) reserve = 1;
+        if (reserve > prop.multiProcessorCount / 2) reserve = prop.multiProcessorCount / 2;
+        h->aux_workgroups = prop.multiProcessorCount - reserve;
         int prio_low = 0, prio_high = 0;
         MI32_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         MI32_HIP(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_low));
@@ -233,6 +241,14 @@ int mi32_set_algo(mi32_handle_t h, int algo)
     if (!h || algo < MI32_ALGO_AUTO || algo > MI32_ALGO_BLOCKED) return MI32_BAD_SHAPE;
     std::lock_guard<std::mutex> lk(h->mu);
     h->algo = algo;
+    return MI32_OK;
+}
+
+int mi32_set_lookahead(mi32_handle_t h, int enable)
+{
+    if (!h) return MI32_BAD_SHAPE;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->lookahead = enable != 0;
     return MI32_OK;
 }
 
@@ -291,9 +307,10 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
     else {
         BlockedExec ex;
         ex.stream = h->stream;
-        ex.aux = h->aux_stream;
+        ex.aux = h->lookahead ? h->aux_stream : nullptr;
         ex.events = h->la_events;
         ex.n_events = h->aux_stream ? 8 : 0;
+        ex.aux_workgroups = h->aux_workgroups;
         ex.prof = h->prof;
         e = blocked_invert(plan_blocked(h, n, batch), d_a, d_inv, batch, d_status, h->ws, ex);
     }

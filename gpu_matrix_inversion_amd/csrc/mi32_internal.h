@@ -96,6 +96,7 @@ struct BlockedExec {
     hipStream_t aux = nullptr;
     hipEvent_t *events = nullptr;
     int n_events = 0;
+    int aux_workgroups = 0;  // grid of the persistent look-ahead kernel: CUs minus the ones kept free
     Profiler *prof = nullptr;
 };
 hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *ws,

@@ -70,6 +70,8 @@ int mi32_set_algo(mi32_handle_t h, int algo);
 /* tuning knobs of the blocked path: sub-panel width (8/16/32) and the outer
  * block width (multiple of the sub-panel width, <= 512); 0 keeps the default */
 int mi32_set_blocking(mi32_handle_t h, int panel_width, int block_width);
+/* look-ahead of the blocked path (second stream; on by default for single matrices of N >= 4096) */
+int mi32_set_lookahead(mi32_handle_t h, int enable);
 /* bytes of device workspace a call of this shape needs (excluding in/out) */
 size_t mi32_workspace_bytes(int n, int batch, int algo);
 /* allocate the workspace up front so that later calls never hipMalloc */
