@@ -56,7 +56,7 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 #define MI32_BW_WPS 3
 #endif
 
-static constexpr int kMaxW = 16;  // widest sub-panel (columns kept in registers)
+static constexpr int kMaxW = 32;  // widest sub-panel (columns kept in registers)
 
 // Panel-kernel geometry: NT threads hold np rows x w columns in registers, rpt rows each.
 // 1024 threads (4 waves/SIMD, <= 128 VGPRs) halve every wave's per-step row work, which is what
@@ -84,9 +84,9 @@ BlockedPlan make_blocked_plan(int n, int w, int bw)
     p.rpt = rpt;
     int wmax = ((nt == 1024) ? 64 : 128) / rpt;  // floats of slab per thread
     if (wmax > kMaxW) wmax = kMaxW;
-    if (w <= 0) w = 16;
+    if (w <= 0) w = 16;  // 32 fits for N <= 2048 and is selectable, but measured slower (4.6 vs 4.2 ms at 2048^2)
     if (w > wmax) w = wmax;
-    w = (w >= 16) ? 16 : (w >= 8 ? 8 : 4);
+    w = (w >= 32) ? 32 : (w >= 16) ? 16 : (w >= 8 ? 8 : 4);
     p.w = w;  // wmax < 4 (np > 16384) is rejected by blocked_supported()
     if (bw <= 0) bw = 256;
     bw = (bw + 127) & ~127;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     __syncthreads();
 
     // accumulators start from the (row-mapped) old values; rows of the block start from 0
-    float16v acc[TM][TN];
+    float16v acc[TM][TN], cin[TM][TN];
     const int lcol = lane & 31;
     const int lhalf = lane >> 5;
 #pragma unroll
@@ -588,7 +588,13 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
                 const int lr = wr * WM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
                 const int grow = row0 + lr;
                 const bool in_block = (grow >= c0 && grow < c0 + kdim);
-                acc[tm][tn][reg] = in_block ? 0.0f : src[(size_t)s_map[lr] * ld + col];
+                const float cval = in_block ? 0.0f : src[(size_t)s_map[lr] * ld + col];
+                if constexpr (COMPACT_G) {
+                    acc[tm][tn][reg] = cval;  // in-block update: the chain starts from the old value
+                } else {
+                    cin[tm][tn][reg] = cval;  // rank-bw update: sum from zero, old value added at the end
+                    acc[tm][tn][reg] = 0.0f;
+                }
             }
         }
 
@@ -667,8 +673,10 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int grow = row0 + wr * WM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                dst[(size_t)grow * ld + col] = acc[tm][tn][reg];
-                if (exp) pt_out[(size_t)(col - pt_col) * np + grow] = acc[tm][tn][reg];
+                float v = acc[tm][tn][reg];
+                if constexpr (!COMPACT_G) v += cin[tm][tn][reg];
+                dst[(size_t)grow * ld + col] = v;
+                if (exp) pt_out[(size_t)(col - pt_col) * np + grow] = v;
             }
         }
 }
@@ -740,23 +748,23 @@ __device__ __forceinline__ void rank_bw_tile(const float *__restrict__ src_all, 
     if (tid < BM) s_map[tid] = map[row0 + tid];
     __syncthreads();
 
-    // accumulators start from the (row-mapped) old values; rows of the block start from 0
+    // The MFMA chain starts from zero and the old values C (row-mapped; 0 for the rows of the block
+    // itself) are added AFTER the k-loop: sum of products first (k ascending), then + C.  That keeps only
+    // the 64 accumulators live across the loop (4 workgroups per CU) and is the more accurate order
+    // (residual 9e-5 instead of 3e-4 at N = 4096: the rounding error of the sum no longer scales with
+    // |C|).  oracle/gj_oracle.c's blocked mirror uses the same order.
+    // (Tried: checkerboarding "C first" / "C last" over the tiles to de-synchronise the memory-bound and
+    // the MFMA phases of co-resident workgroups -- no gain, and it makes the rounding depend on where a
+    // row is stored, which breaks the exact invariance inv(P A) == inv(A) P^T.)
     float16v acc[2][2];
     const int lcol = lane & 31;
     const int lhalf = lane >> 5;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = col0 + wc * 64 + tn * 32 + lcol;
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                const int grow = row0 + lr;
-                const bool in_block = (grow >= c0 && grow < c0 + kdim);
-                acc[tm][tn][reg] = in_block ? 0.0f : src[(size_t)s_map[lr] * ld + col];
-            }
-        }
+            for (int reg = 0; reg < 16; ++reg) acc[tm][tn][reg] = 0.0f;
     MI32_STORE_TILES(0)
     __syncthreads();
 
@@ -765,18 +773,30 @@ __device__ __forceinline__ void rank_bw_tile(const float *__restrict__ src_all, 
         const int buf = t & 1;
         const int ktn = (t + 1 < nk) ? (t + 1) * BK : t * BK;  // last iteration: harmless re-load, keeps the loop branch-free
         MI32_LOAD_TILES(ktn)
+        // fragments of k-pair kk+2 are read from LDS BEFORE the four MFMAs of k-pair kk are issued, so the
+        // LDS latency hides under 256 MFMA cycles (hipcc otherwise emits read -> lgkmcnt(0) -> MFMAs per pair)
+        float af[2], bf[2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) af[tm] = s_a[buf][lhalf * LDA + wr * 64 + tm * 32 + lcol];
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) bf[tn] = s_b[buf][lhalf * LDB + wc * 64 + tn * 32 + lcol];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float af[2], bf[2];
+            float afn[2] = {0.f, 0.f}, bfn[2] = {0.f, 0.f};
+            if (kk + 2 < BK) {
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) af[tm] = s_a[buf][(kk + lhalf) * LDA + wr * 64 + tm * 32 + lcol];
+                for (int tm = 0; tm < 2; ++tm) afn[tm] = s_a[buf][(kk + 2 + lhalf) * LDA + wr * 64 + tm * 32 + lcol];
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) bf[tn] = s_b[buf][(kk + lhalf) * LDB + wc * 64 + tn * 32 + lcol];
+                for (int tn = 0; tn < 2; ++tn) bfn[tn] = s_b[buf][(kk + 2 + lhalf) * LDB + wc * 64 + tn * 32 + lcol];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ABOVE this pair's MFMAs
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { af[q] = afn[q]; bf[q] = bfn[q]; }
         }
         MI32_STORE_TILES(buf ^ 1)
         __syncthreads();
@@ -788,11 +808,24 @@ __device__ __forceinline__ void rank_bw_tile(const float *__restrict__ src_all, 
         for (int tn = 0; tn < 2; ++tn) {
             const int col = col0 + wc * 64 + tn * 32 + lcol;
             const bool exp = (col >= pt_col && col < pt_col + pt_w);  // next sub-panel's column
+            // all 16 old values of this 32x32 sub-tile first (independent loads, in flight together), then
+            // add + store: interleaved, every load would have to wait for the store before it (may-alias).
+            // (Requesting the next sub-tile's values before storing this one needs 16 more registers and
+            // drops the occupancy from 4 to 3 workgroups per CU: measured slower, 118 vs 101 us.)
+            float cv[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                const int grow = row0 + lr;
+                const bool in_block = (grow >= c0 && grow < c0 + kdim);
+                cv[reg] = in_block ? 0.0f : src[(size_t)s_map[lr] * ld + col];
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int grow = row0 + wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                dst[(size_t)grow * ld + col] = acc[tm][tn][reg];
-                if (exp) pt_out[(size_t)(col - pt_col) * np + grow] = acc[tm][tn][reg];
+                const float v = acc[tm][tn][reg] + cv[reg];
+                dst[(size_t)grow * ld + col] = v;
+                if (exp) pt_out[(size_t)(col - pt_col) * np + grow] = v;
             }
         }
 #undef MI32_LOAD_TILES
@@ -863,21 +896,29 @@ __global__ void invert_perm_ld_kernel(const int *__restrict__ orig, int *__restr
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < n) invp[(size_t)b * istride + orig[(size_t)b * istride + c]] = c;
 }
-__global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *__restrict__ w_all, int ld,
+// Whole rows go through LDS: the global read (all np columns of R rows) and the global write (n columns)
+// are both coalesced; the column gather happens inside LDS.  (A direct gather from global memory read
+// 4 scattered bytes per lane: 1.35 ms for 64 x 2048^2, i.e. 1.5 TB/s.)
+__global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *__restrict__ w_all, int ld, int np,
                                                                     size_t wstride, const int *__restrict__ invp,
-                                                                    int istride, int n, float *__restrict__ out)
+                                                                    int istride, int n, int rows_per_block,
+                                                                    float *__restrict__ out)
 {
-    const int b = blockIdx.z;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];  // [rows_per_block][np]
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
     const float *w = w_all + (size_t)b * wstride;
     float *o = out + (size_t)b * n * n;
-    const int c = invp[(size_t)b * istride + j];
-    const int i0 = blockIdx.y * 16;
-#pragma unroll 4
-    for (int u = 0; u < 16; ++u) {
-        const int i = i0 + u;
-        if (i < n) o[(size_t)i * n + j] = w[(size_t)i * ld + c];
+    const int i0 = blockIdx.x * rows_per_block;
+    const int nr = (n - i0 < rows_per_block) ? (n - i0) : rows_per_block;
+    for (int r = 0; r < nr; ++r)
+        for (int c4 = tid * 4; c4 < np; c4 += 1024)
+            *reinterpret_cast<float4 *>(&s_rows[(size_t)r * np + c4]) =
+                *reinterpret_cast<const float4 *>(w + (size_t)(i0 + r) * ld + c4);
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+        const int c = invp[(size_t)b * istride + j];
+        for (int r = 0; r < nr; ++r) o[(size_t)(i0 + r) * n + j] = s_rows[(size_t)r * np + c];
     }
 }
 
@@ -898,6 +939,8 @@ static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, in
         launch_panel<T, R, WW>(p, ws, c0, first, rowsrc, batch, d_status, stream);   \
         return true;                                                                 \
     }
+    MI32_PANEL_CASE(512, 1, 32) MI32_PANEL_CASE(512, 2, 32) MI32_PANEL_CASE(512, 4, 32) MI32_PANEL_CASE(1024, 1, 32)
+    MI32_PANEL_CASE(1024, 2, 32)
     MI32_PANEL_CASE(512, 1, 16) MI32_PANEL_CASE(512, 2, 16) MI32_PANEL_CASE(512, 4, 16) MI32_PANEL_CASE(512, 8, 16)
     MI32_PANEL_CASE(512, 1, 8) MI32_PANEL_CASE(512, 2, 8) MI32_PANEL_CASE(512, 4, 8) MI32_PANEL_CASE(512, 8, 8)
     MI32_PANEL_CASE(512, 1, 4) MI32_PANEL_CASE(512, 2, 4) MI32_PANEL_CASE(512, 4, 4) MI32_PANEL_CASE(512, 8, 4)
@@ -920,7 +963,8 @@ static void launch_inner_update(const BlockedPlan &p, const BlockedWs &ws, const
 #define MI32_INNER(BKV)                                                                                             \
     hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, BKV, true>), grid, dim3(256), 0, stream, x, y, ws.gt,          \
                        ws.tstride, p.np, p.ld, ws.mstride, c0, BKV, C0, ws.submap, 0, ws.pt, ws.tstride, pt_col, p.w, 0, 0)
-    if (p.w == 16) MI32_INNER(16);
+    if (p.w == 32) MI32_INNER(32);
+    else if (p.w == 16) MI32_INNER(16);
     else if (p.w == 8) MI32_INNER(8);
     else MI32_INNER(4);
 #undef MI32_INNER
@@ -1029,8 +1073,14 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     // over ALL np entries: orig is a permutation of [0, np), so every invp[j] is defined and in range
     hipLaunchKernelGGL(invert_perm_ld_kernel, dim3((np + 255) / 256, batch), dim3(256), 0, stream, ws.orig, ws.invp,
                        np, np);
-    hipLaunchKernelGGL(unpermute_columns_ld_kernel, dim3((p.n + 255) / 256, (p.n + 15) / 16, batch), dim3(256), 0,
-                       stream, cur, p.ld, ws.mstride, ws.invp, np, p.n, d_inv);
+    {
+        int rpb = (64 * 1024) / (np * (int)sizeof(float));  // rows per workgroup: at most 64 KiB of LDS
+        if (rpb < 1) rpb = 1;
+        if (rpb > 8) rpb = 8;
+        hipLaunchKernelGGL(unpermute_columns_ld_kernel, dim3((p.n + rpb - 1) / rpb, batch), dim3(256),
+                           (size_t)rpb * np * sizeof(float), stream, cur, p.ld, np, ws.mstride, ws.invp, np, p.n, rpb,
+                           d_inv);
+    }
     return hipGetLastError();
 }
 #endif  // !MI32_STAMPS

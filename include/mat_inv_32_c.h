@@ -67,7 +67,7 @@ int mi32_destroy(mi32_handle_t h);
  * caller keeps ownership of the stream it passes. */
 int mi32_set_stream(mi32_handle_t h, void *hip_stream);
 int mi32_set_algo(mi32_handle_t h, int algo);
-/* tuning knobs of the blocked path: sub-panel width (8/16/32) and the outer
+/* tuning knobs of the blocked path: sub-panel width (4/8/16/32, capped by what fits in registers) and the outer
  * block width (multiple of the sub-panel width, <= 512); 0 keeps the default */
 int mi32_set_blocking(mi32_handle_t h, int panel_width, int block_width);
 /* look-ahead of the blocked path (second stream; on by default for single matrices of N >= 4096) */

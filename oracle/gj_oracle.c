@@ -365,7 +365,10 @@ int gjo_matrix_inv_32_blocked(const float *in, size_t in_len, int n, float *out,
  * lazily through row maps, which moves the same values).  Every accumulation is
  * the k-ascending fmaf chain of v_mfma_f32_32x32x2_f32, so the HIP blocked path
  * with the same (w, bw) reproduces these values bit for bit. */
-static void rank_update(float *m, size_t ld, int n, int r0, int kw, int j_lo, int j_hi, float *rs)
+/* add_last = 0: the fmaf chain starts from the old value (in-block updates);
+ * add_last = 1: the chain starts from zero and the old value is added at the end (rank-bw updates:
+ *               mi32_blocked.hip keeps only the accumulators live across its k-loop that way). */
+static void rank_update(float *m, size_t ld, int n, int r0, int kw, int j_lo, int j_hi, float *rs, int add_last)
 {
     /* rs: kw x n snapshot of rows [r0, r0+kw) */
     for (int k = 0; k < kw; ++k) memcpy(rs + (size_t)k * n, m + (size_t)(r0 + k) * ld, sizeof(float) * n);
@@ -375,9 +378,11 @@ static void rank_update(float *m, size_t ld, int n, int r0, int kw, int j_lo, in
         const int in_block = (i >= r0 && i < r0 + kw);
         for (int j = j_lo; j < j_hi; ++j) {
             if (j >= r0 && j < r0 + kw) continue;
-            float acc = in_block ? 0.0f : mi[j];
+            const float old = in_block ? 0.0f : mi[j];
+            const int last = add_last;
+            float acc = last ? 0.0f : old;
             for (int k = 0; k < kw; ++k) acc = fmaf(g[k], rs[(size_t)k * n + j], acc);
-            mi[j] = acc;
+            mi[j] = last ? acc + old : acc;
         }
     }
 }
@@ -430,9 +435,9 @@ int gjo_matrix_inv_32_blocked2(const float *in, size_t in_len, int n, float *out
                     for (int c = 0; c < kw; ++c) mi[c] = fmaf(-f, prn[c], mi[c]);
                 }
             }
-            if (kb > kw) rank_update(m, ld, n, c0, kw, C0, C0 + kb, rs); /* inside the block */
+            if (kb > kw) rank_update(m, ld, n, c0, kw, C0, C0 + kb, rs, 0); /* inside the block */
         }
-        if (kb < n) rank_update(m, ld, n, C0, kb, 0, n, rs); /* everything outside the block */
+        if (kb < n) rank_update(m, ld, n, C0, kb, 0, n, rs, 1); /* everything outside the block */
     }
     for (int i = 0; i < n; ++i)
         for (int c = 0; c < n; ++c) out[(size_t)i * n + orig[c]] = m[(size_t)i * ld + c];

@@ -82,13 +82,14 @@ def test_blocked_bit_identical_to_blocked_mirror(oracle, inv_blocked, n):
         if kind == "hollow" and n == 1:
             continue
         a = dist_matrix(kind, n, 8000 + n)
-        want = oracle.matrix_inv_32_blocked2(a, n, 16, 256)
+        w, bw = inv_blocked.resolved_blocking(n, 1)
+        want = oracle.matrix_inv_32_blocked2(a, n, w, bw)
         got, st = run(inv_blocked, a)
         assert st[0] == 0
         assert np.array_equal(got.reshape(-1), want), (kind, n, np.abs(got.reshape(-1) - want).max())
 
 
-@pytest.mark.parametrize("w,bw", [(16, 128), (8, 128), (4, 256), (8, 384), (16, 512)])
+@pytest.mark.parametrize("w,bw", [(32, 128), (16, 128), (8, 128), (4, 256), (8, 384), (16, 512), (32, 256)])
 def test_blocked_other_blockings(oracle, w, bw):
     inv = g.Inverter(algo="blocked", panel_width=w, block_width=bw)
     try:
@@ -181,7 +182,7 @@ def test_batched_with_a_singular_member(oracle, inv_sweep, inv_blocked):
     mats = np.stack([gate_matrix(n, 900 + b) for b in range(B)])
     mats[3] = 1.0  # rank-1: singular
     for inv, mirror in ((inv_sweep, lambda m: oracle.matrix_inv_32(m, n)),
-                        (inv_blocked, lambda m: oracle.matrix_inv_32_blocked2(m, n, 16, 256))):
+                        (inv_blocked, lambda m: oracle.matrix_inv_32_blocked2(m, n, *inv_blocked.resolved_blocking(n, B)))):
         got, st = run(inv, mats)
         assert list(st) == [0, 0, 0, 2, 0, 0]
         for b in range(B):
