@@ -290,7 +290,11 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], 
 #pragma unroll
     for (int k = 0; k < RPT; ++k) col[k] = a[k][0];  // the pivot column is always register 0
     int own_lane = -1, own_k = 0;
+#ifdef MI32_ABL_NO_SEARCH
+    if (wave_active && tid == 12345) {
+#else
     if (wave_active) {
+#endif
         // candidate key of register row k: bits of |a| if the row is a valid candidate, else 0.  It is
         // recomputed in the second pass rather than kept: 2*RPT fewer live registers, which is what
         // lets the RPT = 16 instance (N = 16384) fit the 128-VGPR budget of 1024 threads.
@@ -307,7 +311,11 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], 
             bm = mk > bm ? mk : bm;
         }
         MI32_STAMP(r, 1);
+#ifdef MI32_ABL_NO_DPP
+        const unsigned wm = (unsigned)__builtin_amdgcn_readlane((int)bm, 5);
+#else
         const unsigned wm = wave_max_u32(bm);
+#endif
         unsigned bi = 0x7fffffffu;
         int kb = 0;  // which of this lane's rows is its candidate
 #pragma unroll
@@ -347,7 +355,11 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], 
             __builtin_amdgcn_wave_barrier();
             const float cpiv = sh.cand[wave_u][0];
             const float num = (lane < W) ? ((lane == 0) ? 1.0f : sh.cand[wave_u][lane]) : 0.0f;
+#ifdef MI32_ABL_NO_DIV
+            const float qv = num * cpiv;
+#else
             const float qv = num / cpiv;
+#endif
             if (lane < W) sh.prn[par][wave_u][lane] = qv;
             if (lane == 0) {
                 sh.piv[par][wave_u] = cpiv;
@@ -357,7 +369,9 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], 
         }
     }
     MI32_STAMP(r, 3);
+#ifndef MI32_ABL_NO_BARRIER
     __syncthreads();
+#endif
     MI32_STAMP(r, 4);
     const unsigned long long key = sh.key[r];
     const int hs = sh.hold[r];  // the register row that currently holds position `slot`
@@ -384,6 +398,9 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], 
     // -- fixColumn on the slab, branch-free, rotating left by one register: column c lands in register
     //    c-1; the pivot column (register 0, the implicit identity column: entry 0 in every other row)
     //    lands in register W-1.  The pivot row itself is overwritten right after.
+#ifdef MI32_ABL_NO_FMA
+    if (tid == 12345)
+#endif
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const float f = col[k];
