@@ -217,7 +217,7 @@ def main():
             pmc_path = os.path.join(ROOT, "profiles", "round1", "pmc_rank_bw_n4096.json")
             if n == 4096 and batch == 1 and bw == 256 and os.path.exists(pmc_path):
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch_corrected")
-            roof = {"bound": "mfma", "kernel": "gj_rank_bw_update_kernel", "achieved": ach,
+            roof = {"bound": "mfma", "kernel": "gj_rank_bw2_kernel", "achieved": ach,
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
                     "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt / args.steps,
                     "algorithmic_flops_per_launch": flops,

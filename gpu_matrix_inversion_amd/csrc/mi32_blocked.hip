@@ -43,18 +43,20 @@
 #include <cstdlib>
 
 #include "mi32_internal.h"
+#include "mi32_rank_bw.h"
 
 namespace mi32 {
 
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-// k-tile depth and waves/SIMD of the pipelined rank-bw update (tunable at build time)
+// k-tile depth and waves/SIMD of the rank-bw update (mi32_rank_bw.h; tunable at build time)
 #ifndef MI32_BW_BK
 #define MI32_BW_BK 16
 #endif
 #ifndef MI32_BW_WPS
 #define MI32_BW_WPS 3
 #endif
+static constexpr int kMaxBW = 512;  // widest outer block (rows of the transposed panel Gk)
 
 static constexpr int kMaxW = 32;  // widest sub-panel (columns kept in registers)
 
@@ -101,6 +103,8 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct BlockedWs {
     float *m0, *m1;   // the two working copies, np x ld each
     float *pt, *gt;   // compact transposed panels, kMaxW x np each: panel kernel input / output
+    float *gk;        // the block's panel G transposed, bw x np: A operand of the rank-bw update
+    size_t gkstride;  // floats per matrix in gk
     int *submap, *rowsrc[2], *orig, *invp;  // rowsrc is double-buffered across blocks (look-ahead)
     size_t mstride;   // floats per matrix in m0/m1
     size_t tstride;   // floats per matrix in pt/gt
@@ -120,6 +124,9 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
     off += tbytes * batch;
     if (o) o->gt = (float *)(c + off);
     off += tbytes * batch;
+    const size_t gkbytes = align256((size_t)(p.bw < kMaxBW ? p.bw : kMaxBW) * p.np * sizeof(float));
+    if (o) { o->gk = (float *)(c + off); o->gkstride = gkbytes / sizeof(float); }
+    off += gkbytes * batch;
     if (o) o->submap = (int *)(c + off);
     off += ibytes;
     if (o) o->rowsrc[0] = (int *)(c + off);
@@ -698,214 +705,6 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
         }
 }
 
-// ---- the rank-bw update, pipelined --------------------------------------------------
-// Same arithmetic as gj_rank_update_kernel<128,128,32,false> (one k-ascending MFMA chain per output
-// element, so results are bit-identical), restructured for the matrix pipe:
-//  * register-staged double buffering: the global loads of k-tile t+1 are issued before the 64 MFMAs of
-//    k-tile t and written to the other LDS buffer after them -> one barrier per k-tile instead of two,
-//    and the loads' latency hides under the MFMAs;
-//  * XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) cover a compact (T/2) x (T/4)
-//    sub-grid of tiles, so that XCD's 4 MiB L2 holds the A and B panels its tiles re-read.
-template <int BK>
-__device__ __forceinline__ void rank_bw_tile(const float *__restrict__ src_all, float *__restrict__ dst_all,
-                                             const float *__restrict__ g_all, size_t gstride, int np, int ld,
-                                             size_t mstride, int c0, int kdim, const int *__restrict__ map_all,
-                                             int copy_panel, float *__restrict__ pt_out_all, size_t tstride,
-                                             int pt_col, int pt_w, int skip_lo, int skip_hi, int b, int rt, int ct,
-                                             float (&s_a)[2][BK * (128 + (BK == 32 ? 1 : 2))],
-                                             float (&s_b)[2][BK * (128 + 4)], int (&s_map)[128])
-{
-    constexpr int BM = 128, BN = 128;
-    constexpr int NQ = BK / 8;  // float4 per thread per operand tile
-    constexpr int LDA = BM + (BK == 32 ? 1 : 2), LDB = BN + 4;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int row0 = rt * BM, col0 = ct * BN;
-    const float *src = src_all + (size_t)b * mstride;
-    float *dst = dst_all + (size_t)b * mstride;
-    const float *g = g_all + (size_t)b * gstride;
-    const int *map = map_all + (size_t)b * np;
-    float *pt_out = pt_out_all + (size_t)b * tstride;
-
-    if (col0 >= skip_lo && col0 < skip_hi) return;
-    if (col0 >= c0 && col0 + BN <= c0 + kdim) {  // tile inside the panel: those columns are G itself
-        if (copy_panel) {
-            for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
-                const int rr = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
-                *reinterpret_cast<float4 *>(dst + (size_t)(row0 + rr) * ld + col0 + c4) =
-                    *reinterpret_cast<const float4 *>(g + (size_t)(row0 + rr) * ld + col0 + c4);
-            }
-        }
-        return;
-    }
-
-    // staging: A tile 128 rows x BK k (float4 idx: row = idx / (BK/4), k4 = idx % (BK/4)),
-    //          B tile BK k x 128 columns (k = idx / 32, c4 = idx % 32); idx = tid + 256 q, q < BK/8
-    typedef float f4v __attribute__((ext_vector_type(4)));  // native vector: HIP's float4 struct in an array goes to scratch
-    f4v ra[NQ], rb[NQ];
-#define MI32_LOAD_TILES(KT)                                                                                        \
-    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                               \
-        const int idx = tid + q * 256;                                                                             \
-        ra[q] = *reinterpret_cast<const f4v *>(g + (size_t)(row0 + idx / (BK / 4)) * ld + c0 + (KT) +              \
-                                               (idx % (BK / 4)) * 4);                                              \
-        rb[q] = *reinterpret_cast<const f4v *>(src + (size_t)map[c0 + (KT) + (idx >> 5)] * ld + col0 +             \
-                                                  (idx & 31) * 4);                                                 \
-    }
-#define MI32_STORE_TILES(BUF)                                                                  \
-    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                           \
-        const int idx = tid + q * 256;                                                         \
-        float *pa = &s_a[BUF][((idx % (BK / 4)) * 4) * LDA + idx / (BK / 4)];                  \
-        pa[0] = ra[q][0]; pa[LDA] = ra[q][1]; pa[2 * LDA] = ra[q][2]; pa[3 * LDA] = ra[q][3];  \
-        *reinterpret_cast<f4v *>(&s_b[BUF][(idx >> 5) * LDB + (idx & 31) * 4]) = rb[q];        \
-    }
-
-    MI32_LOAD_TILES(0)
-    if (tid < BM) s_map[tid] = map[row0 + tid];
-    __syncthreads();
-
-    // The MFMA chain starts from zero and the old values C (row-mapped; 0 for the rows of the block
-    // itself) are added AFTER the k-loop: sum of products first (k ascending), then + C.  That keeps only
-    // the 64 accumulators live across the loop (4 workgroups per CU) and is the more accurate order
-    // (residual 9e-5 instead of 3e-4 at N = 4096: the rounding error of the sum no longer scales with
-    // |C|).  oracle/gj_oracle.c's blocked mirror uses the same order.
-    // (Tried: checkerboarding "C first" / "C last" over the tiles to de-synchronise the memory-bound and
-    // the MFMA phases of co-resident workgroups -- no gain, and it makes the rounding depend on where a
-    // row is stored, which breaks the exact invariance inv(P A) == inv(A) P^T.)
-    float16v acc[2][2];
-    const int lcol = lane & 31;
-    const int lhalf = lane >> 5;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[tm][tn][reg] = 0.0f;
-    MI32_STORE_TILES(0)
-    __syncthreads();
-
-    const int nk = kdim / BK;
-    for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
-        const int ktn = (t + 1 < nk) ? (t + 1) * BK : t * BK;  // last iteration: harmless re-load, keeps the loop branch-free
-        MI32_LOAD_TILES(ktn)
-        // fragments of k-pair kk+2 are read from LDS BEFORE the four MFMAs of k-pair kk are issued, so the
-        // LDS latency hides under 256 MFMA cycles (hipcc otherwise emits read -> lgkmcnt(0) -> MFMAs per pair)
-        float af[2], bf[2];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) af[tm] = s_a[buf][lhalf * LDA + wr * 64 + tm * 32 + lcol];
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) bf[tn] = s_b[buf][lhalf * LDB + wc * 64 + tn * 32 + lcol];
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float afn[2] = {0.f, 0.f}, bfn[2] = {0.f, 0.f};
-            if (kk + 2 < BK) {
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm) afn[tm] = s_a[buf][(kk + 2 + lhalf) * LDA + wr * 64 + tm * 32 + lcol];
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) bfn[tn] = s_b[buf][(kk + 2 + lhalf) * LDB + wc * 64 + tn * 32 + lcol];
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ABOVE this pair's MFMAs
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { af[q] = afn[q]; bf[q] = bfn[q]; }
-        }
-        MI32_STORE_TILES(buf ^ 1)
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = col0 + wc * 64 + tn * 32 + lcol;
-            const bool exp = (col >= pt_col && col < pt_col + pt_w);  // next sub-panel's column
-            // all 16 old values of this 32x32 sub-tile first (independent loads, in flight together), then
-            // add + store: interleaved, every load would have to wait for the store before it (may-alias).
-            // (Requesting the next sub-tile's values before storing this one needs 16 more registers and
-            // drops the occupancy from 4 to 3 workgroups per CU: measured slower, 118 vs 101 us.)
-            float cv[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                const int grow = row0 + lr;
-                const bool in_block = (grow >= c0 && grow < c0 + kdim);
-                cv[reg] = in_block ? 0.0f : src[(size_t)s_map[lr] * ld + col];
-            }
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int grow = row0 + wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                const float v = acc[tm][tn][reg] + cv[reg];
-                dst[(size_t)grow * ld + col] = v;
-                if (exp) pt_out[(size_t)(col - pt_col) * np + grow] = v;
-            }
-        }
-#undef MI32_LOAD_TILES
-#undef MI32_STORE_TILES
-}
-
-// XCD-aware tile order: workgroups that share an XCD (linear id % 8) cover a compact (T/2) x (T/4)
-// sub-grid of tiles, so that XCD's 4 MiB L2 holds the A and B panels its tiles re-read.
-__device__ __forceinline__ void rank_bw_tile_of(int id, int T, int &rt, int &ct)
-{
-    if ((T & 7) == 0) {
-        const int xcd = id & 7, idx = id >> 3;
-        const int tr = T / 2, tc = T / 4;
-        rt = (xcd >> 2) * tr + idx / tc;
-        ct = (xcd & 3) * tc + idx % tc;
-    } else {
-        rt = id / T;
-        ct = id % T;
-    }
-}
-
-template <int BK, int WPS>
-__global__ __launch_bounds__(256, WPS) void gj_rank_bw_update_kernel(const float *__restrict__ src_all,
-                                                                     float *__restrict__ dst_all,
-                                                                     const float *__restrict__ g_all, size_t gstride,
-                                                                     int np, int ld, size_t mstride, int c0, int kdim,
-                                                                     const int *__restrict__ map_all, int copy_panel,
-                                                                     float *__restrict__ pt_out_all, size_t tstride,
-                                                                     int pt_col, int pt_w, int skip_lo, int skip_hi)
-{
-    __shared__ float s_a[2][BK * (128 + (BK == 32 ? 1 : 2))];
-    __shared__ __attribute__((aligned(16))) float s_b[2][BK * (128 + 4)];
-    __shared__ int s_map[128];
-    int rt, ct;
-    rank_bw_tile_of(blockIdx.x, np / 128, rt, ct);
-    rank_bw_tile<BK>(src_all, dst_all, g_all, gstride, np, ld, mstride, c0, kdim, map_all, copy_panel, pt_out_all,
-                     tstride, pt_col, pt_w, skip_lo, skip_hi, blockIdx.y, rt, ct, s_a, s_b, s_map);
-}
-
-// Persistent, residency-limited flavour for the look-ahead half: gridDim.x workgroups walk all the tiles.
-// It is launched with enough dynamic LDS that only ONE workgroup fits on a CU and with fewer workgroups
-// than CUs, so a known number of CUs stays entirely free for the critical-path kernels of the main
-// stream (the panel kernel needs a whole CU); stream priorities cannot give that guarantee and a CU
-// mask serialises the queues.
-template <int BK>
-__global__ __launch_bounds__(256, 1) void gj_rank_bw_update_persistent_kernel(
-    const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
-    int np, int ld, size_t mstride, int c0, int kdim, const int *__restrict__ map_all, int copy_panel,
-    float *__restrict__ pt_out_all, size_t tstride, int pt_col, int pt_w, int skip_lo, int skip_hi)
-{
-    __shared__ float s_a[2][BK * (128 + (BK == 32 ? 1 : 2))];
-    __shared__ __attribute__((aligned(16))) float s_b[2][BK * (128 + 4)];
-    __shared__ int s_map[128];
-    const int T = np / 128;
-    for (int id = blockIdx.x; id < T * T; id += gridDim.x) {
-        int rt, ct;
-        rank_bw_tile_of(id, T, rt, ct);
-        rank_bw_tile<BK>(src_all, dst_all, g_all, gstride, np, ld, mstride, c0, kdim, map_all, copy_panel, pt_out_all,
-                         tstride, pt_col, pt_w, skip_lo, skip_hi, blockIdx.y, rt, ct, s_a, s_b, s_map);
-        __syncthreads();  // the next tile re-uses the LDS buffers
-    }
-}
-
 // ---- getInvertedMatrix counterpart: undo the column permutation ----------------
 __global__ void invert_perm_ld_kernel(const int *__restrict__ orig, int *__restrict__ invp, int n, int istride)
 {
@@ -1012,6 +811,23 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
         if ((e = hipEventRecord(ex.events[0], ex.aux)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(stream, ex.events[0], 0)) != hipSuccess) return e;
     }
+    // dynamic LDS of the rank-bw kernels: operand stages + maps; the persistent flavour asks for more than half
+    // a CU's LDS so that at most one of its workgroups is resident per CU
+    const size_t lds_persistent = 84 * 1024;
+    {
+        static bool attr_set_dev[64] = {};  // function attributes are per device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        bool &attr_set = attr_set_dev[dev & 63];
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)rank_bw2_lds_bytes<MI32_BW_BK>(kMaxBW));
+            (void)hipFuncSetAttribute((const void *)gj_rank_bw2_persistent_kernel<MI32_BW_BK>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_persistent);
+            attr_set = true;
+        }
+    }
     float *cur = ws.m0, *oth = ws.m1;
     bool pending_b = false;  // a (B) half is in flight on the second stream
     int blk = 0, ev = 0;
@@ -1042,6 +858,11 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 if ((e = hipStreamWaitEvent(stream, ex.events[ev], 0)) != hipSuccess) return e;
                 pending_b = false;
             }
+            {   // A operand of the rank-bw update: the block's panel, k-major (mi32_rank_bw.h)
+                ProfScope ps(prof, KC_TRANSPOSE, stream);
+                hipLaunchKernelGGL(gj_panel_transpose_kernel, dim3(np / 64, kb / 64, batch), dim3(256), 0, stream, x,
+                                   ws.mstride, np, p.ld, C0, ws.gk, ws.gkstride);
+            }
             if (lookahead && has_next) {
                 {   // (A): the next block's columns, on the main stream; exports the next sub-panel
                     ProfScope ps(prof, KC_UPDATE_OUT, stream);
@@ -1057,26 +878,21 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 if ((e = hipStreamWaitEvent(ex.aux, e_panel, 0)) != hipSuccess) return e;
                 {
                     ProfScope ps(prof, KC_UPDATE_OUT, ex.aux);
-                    // persistent flavour: aux_workgroups (< number of CUs) workgroups, padded with dynamic LDS
-                    // so that one CU holds at most one of them -> the remaining CUs stay free for the main stream
-                    constexpr int kPadLds = 48 * 1024;
-                    static bool attr_set = false;
-                    if (!attr_set) {
-                        (void)hipFuncSetAttribute((const void *)gj_rank_bw_update_persistent_kernel<MI32_BW_BK>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kPadLds);
-                        attr_set = true;
-                    }
-                    hipLaunchKernelGGL((gj_rank_bw_update_persistent_kernel<MI32_BW_BK>), dim3(ex.aux_workgroups, batch),
-                                       dim3(256), kPadLds, ex.aux, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb,
-                                       rowsrc, copy, ws.pt, ws.tstride, -(1 << 30), p.w, next, next + kb_next);
+                    // persistent flavour: aux_workgroups (< number of CUs) workgroups, with so much dynamic LDS
+                    // that one CU holds at most one of them -> the remaining CUs stay free for the main stream
+                    hipLaunchKernelGGL((gj_rank_bw2_persistent_kernel<MI32_BW_BK>), dim3(ex.aux_workgroups, batch),
+                                       dim3(256), lds_persistent, ex.aux, cur, oth, x, ws.mstride, ws.gk, ws.gkstride, np,
+                                       p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt, ws.tstride, -(1 << 30), p.w, next,
+                                       next + kb_next);
                 }
                 if ((e = hipEventRecord(ex.events[ev], ex.aux)) != hipSuccess) return e;
                 pending_b = true;
             } else {
                 ProfScope ps(prof, KC_UPDATE_OUT, stream);
-                hipLaunchKernelGGL((gj_rank_bw_update_kernel<MI32_BW_BK, MI32_BW_WPS>), dim3((np / 128) * (np / 128), batch), dim3(256), 0, stream,
-                                   cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt,
-                                   ws.tstride, pt_col, p.w, 0, 0);
+                hipLaunchKernelGGL((gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS>), dim3((np / 128) * (np / 128), batch),
+                                   dim3(256), rank_bw2_lds_bytes<MI32_BW_BK>(kb), stream, cur, oth, x, ws.mstride, ws.gk,
+                                   ws.gkstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt, ws.tstride, pt_col, p.w,
+                                   0, 0);
             }
             float *t = cur; cur = oth; oth = t;
         } else {

@@ -282,7 +282,7 @@ int mi32_resolve_blocking(mi32_handle_t h, int n, int batch, int *panel_width, i
 
 const char *mi32_dominant_kernel(int algo)
 {
-    return algo == MI32_ALGO_SWEEP ? "gj_sweep_step_kernel" : "gj_rank_bw_update_kernel";
+    return algo == MI32_ALGO_SWEEP ? "gj_sweep_step_kernel" : "gj_rank_bw2_kernel";
 }
 
 int mi32_reserve(mi32_handle_t h, int n, int batch)

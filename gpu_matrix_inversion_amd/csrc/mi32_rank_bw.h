@@ -1,0 +1,249 @@
+// mi32_rank_bw.h -- the rank-bw update of the blocked path, second generation (gfx950 only).
+//
+//   dst[i][j] = (i in [c0,c0+kdim) ? 0 : src[map[i]][j]) + sum_k G[i][k] * src[map[c0+k]][j]
+//
+// i.e. fixColumnKernel (/root/reference/Matlab/mat_inv_32/mat_inv_32/mat_inv_32.cpp:13-57) for all
+// columns outside the current block of kdim pivots, with the block's kdim eliminations applied at once
+// on the fp32 matrix cores.  Same arithmetic as gj_rank_bw_update_kernel in mi32_blocked.hip (one
+// k-ascending v_mfma_f32_32x32x2_f32 chain per output element from zero, old value added last), so the
+// results are bit-identical; what changes is how the operands reach the matrix pipe:
+//
+//  * both operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no
+//    ds_write instructions, and the loads of k-tile t+1 are in flight during the MFMAs of k-tile t;
+//  * for that the A operand (the block's panel G, np x kdim, row-major in the working copy) is first
+//    transposed into a compact k-major array Gk[k][row] by gj_panel_transpose_kernel, so that an A tile
+//    is [BK][128] contiguous rows exactly like a B tile -- the LDS image of an LDS-DMA is lane-linear,
+//    it cannot transpose;
+//  * the row map of the kdim pivot rows (the B operand's row gather) is read ONCE into LDS; the first
+//    kernel fetched map[c0+k] from global memory inside every k-tile, a dependent L2 round trip in
+//    front of every B load that all co-resident workgroups hit in lock-step.
+#pragma once
+#include "mi32_internal.h"
+
+namespace mi32 {
+
+typedef float rb_float16v __attribute__((ext_vector_type(16)));
+typedef float rb_f4v __attribute__((ext_vector_type(4)));
+
+// Gk[k][row] = g[row][c0 + k], k < kdim: 64 x 64 tiles through LDS, both global sides coalesced.
+__global__ __launch_bounds__(256) void gj_panel_transpose_kernel(const float *__restrict__ g_all, size_t gstride, int np,
+                                                                  int ld, int c0, float *__restrict__ gk_all,
+                                                                  size_t gkstride)
+{
+    __shared__ float t[64][65];
+    const int b = blockIdx.z;
+    const int row0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const float *g = g_all + (size_t)b * gstride;
+    float *gk = gk_all + (size_t)b * gkstride;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (tid >> 4) + 16 * q, c4 = (tid & 15) * 4;
+        const rb_f4v v = *reinterpret_cast<const rb_f4v *>(g + (size_t)(row0 + r) * ld + c0 + k0 + c4);
+        t[r][c4] = v[0]; t[r][c4 + 1] = v[1]; t[r][c4 + 2] = v[2]; t[r][c4 + 3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = (tid >> 4) + 16 * q, r4 = (tid & 15) * 4;
+        rb_f4v v;
+        v[0] = t[r4][k]; v[1] = t[r4 + 1][k]; v[2] = t[r4 + 2][k]; v[3] = t[r4 + 3][k];
+        *reinterpret_cast<rb_f4v *>(gk + (size_t)(k0 + k) * np + row0 + r4) = v;
+    }
+}
+
+// One LDS-DMA: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at a wave-uniform base.
+__device__ __forceinline__ void rb_glds16(const float *gsrc, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// LDS footprint of one workgroup of gj_rank_bw2_kernel<BK>: two stages of (A tile + B tile), the C-row
+// map of the tile and the pivot-row map of the block.
+template <int BK>
+constexpr size_t rank_bw2_lds_bytes(int kdim)
+{
+    return (size_t)(2 * 2 * BK * 128) * sizeof(float) + (size_t)(128 + kdim) * sizeof(int);
+}
+
+// XCD-aware tile order (see mi32_blocked.hip): workgroups that share an XCD cover a compact sub-grid.
+__device__ __forceinline__ void rb_tile_of(int id, int T, int &rt, int &ct)
+{
+    if ((T & 7) == 0) {
+        const int xcd = id & 7, idx = id >> 3;
+        const int tr = T / 2, tc = T / 4;
+        rt = (xcd >> 2) * tr + idx / tc;
+        ct = (xcd & 3) * tc + idx % tc;
+    } else {
+        rt = id / T;
+        ct = id % T;
+    }
+}
+
+// One 128 x 128 output tile (rt, ct) of matrix b.  rb_smem: rank_bw2_lds_bytes<BK>(kdim) bytes of LDS.
+template <int BK>
+__device__ __forceinline__ void rank_bw2_tile(
+    const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
+    const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
+    const int *__restrict__ map_all, int copy_panel, float *__restrict__ pt_out_all, size_t tstride, int pt_col,
+    int pt_w, int skip_lo, int skip_hi, int b, int rt, int ct, float *rb_smem)
+{
+    constexpr int BM = 128, BN = 128;
+    constexpr int ND = BK / 8;  // LDS-DMA instructions per wave per operand per stage (each moves 2 k-rows)
+    float *s_a = rb_smem;                    // [2][BK][128]
+    float *s_b = rb_smem + 2 * BK * 128;     // [2][BK][128]
+    int *s_map = reinterpret_cast<int *>(rb_smem + 4 * BK * 128);  // [128]  C rows of this tile
+    int *s_bmap = s_map + 128;               // [kdim] pivot rows of the block
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int row0 = rt * BM, col0 = ct * BN;
+    const float *src = src_all + (size_t)b * mstride;
+    float *dst = dst_all + (size_t)b * mstride;
+    const float *gk = gk_all + (size_t)b * gkstride;
+    const int *map = map_all + (size_t)b * np;
+    float *pt_out = pt_out_all + (size_t)b * tstride;
+
+    if (col0 >= skip_lo && col0 < skip_hi) return;
+    if (col0 >= c0 && col0 + BN <= c0 + kdim) {  // tile inside the panel: those columns are G itself
+        if (copy_panel) {
+            const float *g = g_all + (size_t)b * gstride;
+            for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+                const int rr = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+                *reinterpret_cast<rb_f4v *>(dst + (size_t)(row0 + rr) * ld + col0 + c4) =
+                    *reinterpret_cast<const rb_f4v *>(g + (size_t)(row0 + rr) * ld + col0 + c4);
+            }
+        }
+        return;
+    }
+
+    if (tid < BM) s_map[tid] = map[row0 + tid];
+    for (int i = tid; i < kdim; i += 256) s_bmap[i] = map[c0 + i];
+    __syncthreads();
+
+    // per-lane source addresses of this wave's DMA slices: k-rows 2*(wave*ND + i) + (lane >> 5) of a stage
+    const int lk = lane >> 5, lc4 = (lane & 31) * 4;
+    const float *a_src = gk + (size_t)lk * np + row0 + lc4;  // + (kt + 2 * (wave * ND + i)) * np
+    const float *b_col = src + col0 + lc4;                   // + s_bmap[kt + 2 * (wave * ND + i) + lk] * ld
+
+#define MI32_RB_ISSUE(STAGE, KT)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                   \
+        const int kr = 2 * (wave * ND + i);                                                            \
+        rb_glds16(a_src + (size_t)((KT) + kr) * np, s_a + ((STAGE) * BK + kr) * 128);                  \
+        rb_glds16(b_col + (size_t)s_bmap[(KT) + kr + lk] * ld, s_b + ((STAGE) * BK + kr) * 128);       \
+    }
+
+    rb_float16v acc[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[tm][tn][reg] = 0.0f;
+
+    const int lcol = lane & 31;
+    const int lhalf = lane >> 5;
+    const int nk = kdim / BK;
+    const bool tile_in_block = (row0 >= c0 && row0 < c0 + kdim);
+    MI32_RB_ISSUE(0, 0)
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        // stage t has landed for this wave's DMAs; after the barrier for everyone's, and every wave is done
+        // reading the other buffer (k-tile t-1), which the next DMA overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nk) { MI32_RB_ISSUE(buf ^ 1, (t + 1) * BK) }
+        const float *pa = s_a + buf * BK * 128 + lhalf * 128 + wr * 64 + lcol;
+        const float *pb = s_b + buf * BK * 128 + lhalf * 128 + wc * 64 + lcol;
+        float af[2], bf[2];
+        af[0] = pa[0]; af[1] = pa[32];
+        bf[0] = pb[0]; bf[1] = pb[32];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float afn[2] = {0.f, 0.f}, bfn[2] = {0.f, 0.f};
+            if (kk + 2 < BK) {
+                afn[0] = pa[(kk + 2) * 128]; afn[1] = pa[(kk + 2) * 128 + 32];
+                bfn[0] = pb[(kk + 2) * 128]; bfn[1] = pb[(kk + 2) * 128 + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ABOVE this pair's MFMAs
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { af[q] = afn[q]; bf[q] = bfn[q]; }
+        }
+    }
+#undef MI32_RB_ISSUE
+
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = col0 + wc * 64 + tn * 32 + lcol;
+            const bool exp = (col >= pt_col && col < pt_col + pt_w);  // next sub-panel's column
+            // the old values C (row-mapped); the rows of the block itself start from 0.  Block bounds are
+            // multiples of 128, so a whole tile is either inside the block or outside it.
+            float cv[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) cv[reg] = 0.0f;
+            if (!tile_in_block) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                    cv[reg] = src[(size_t)s_map[lr] * ld + col];
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int grow = row0 + wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                const float v = acc[tm][tn][reg] + cv[reg];
+                dst[(size_t)grow * ld + col] = v;
+                if (exp) pt_out[(size_t)(col - pt_col) * np + grow] = v;
+            }
+        }
+}
+
+
+template <int BK, int WPS>
+__global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
+    const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
+    const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
+    const int *__restrict__ map_all, int copy_panel, float *__restrict__ pt_out_all, size_t tstride, int pt_col,
+    int pt_w, int skip_lo, int skip_hi)
+{
+    extern __shared__ __attribute__((aligned(16))) float rb_smem[];
+    int rt, ct;
+    rb_tile_of(blockIdx.x, np / 128, rt, ct);
+    rank_bw2_tile<BK>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all, copy_panel,
+                      pt_out_all, tstride, pt_col, pt_w, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
+}
+
+// Persistent, residency-limited flavour for the look-ahead half (see blocked_invert): gridDim.x workgroups
+// walk all the tiles.  It is launched with enough dynamic LDS that only ONE workgroup fits on a CU and with
+// fewer workgroups than CUs, so a known number of CUs stays entirely free for the critical-path kernels
+// of the main stream (the panel kernel needs a whole CU); stream priorities cannot give that guarantee
+// and a CU mask serialises the queues.
+template <int BK>
+__global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
+    const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
+    const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
+    const int *__restrict__ map_all, int copy_panel, float *__restrict__ pt_out_all, size_t tstride, int pt_col,
+    int pt_w, int skip_lo, int skip_hi)
+{
+    extern __shared__ __attribute__((aligned(16))) float rb_smem[];
+    const int T = np / 128;
+    for (int id = blockIdx.x; id < T * T; id += gridDim.x) {
+        int rt, ct;
+        rb_tile_of(id, T, rt, ct);
+        rank_bw2_tile<BK>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
+                          copy_panel, pt_out_all, tstride, pt_col, pt_w, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
+        __syncthreads();  // the next tile re-uses the LDS buffers and maps
+    }
+}
+
+}  // namespace mi32

@@ -80,12 +80,13 @@ def test_workspace_sizes():
     blocked = lib.mi32_workspace_bytes(n, 1, _lib.ALGO_BLOCKED)
     # two working copies of the N x N matrix (the reference holds two N x 2N panels + N x N)
     assert 2 * n * n * 4 <= sweep < 2 * n * n * 4 + (1 << 20)
-    assert 2 * n * n * 4 <= blocked < 2 * n * (n + 64) * 4 + (2 << 20)  # rows padded by 256 B, + compact panels and maps
+    # rows padded by 256 B, + compact panels and maps, + the transposed block panel (block width 256 x N)
+    assert 2 * n * n * 4 <= blocked < 2 * n * (n + 64) * 4 + 256 * n * 4 + (2 << 20)
     assert lib.mi32_workspace_bytes(0, 1, 0) == 0
     # padding to a multiple of 128 in the blocked path
     assert lib.mi32_workspace_bytes(1000, 1, _lib.ALGO_BLOCKED) >= 2 * 1024 * 1024 * 4
     assert lib.mi32_dominant_kernel(_lib.ALGO_SWEEP) == b"gj_sweep_step_kernel"
-    assert lib.mi32_dominant_kernel(_lib.ALGO_BLOCKED) == b"gj_rank_bw_update_kernel"
+    assert lib.mi32_dominant_kernel(_lib.ALGO_BLOCKED) == b"gj_rank_bw2_kernel"
 
 
 @pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
