@@ -41,6 +41,7 @@
 // checks: inv(diag(A, I)) = diag(inv(A), I); a real column only ever takes its
 // pivot from the real rows, so the padding is never swapped into the matrix.
 #include <cstdlib>
+#include <utility>
 
 #include "mi32_internal.h"
 #include "mi32_rank_bw.h"
@@ -102,7 +103,8 @@ bool blocked_supported(int n) { return n > 0 && ((n + 127) & ~127) <= 16384; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct BlockedWs {
     float *m0, *m1;   // the two working copies, np x ld each
-    float *pt, *gt;   // compact transposed panels, kMaxW x np each: panel kernel input / output
+    float *pt[2], *gt;  // compact transposed panels, kMaxW x np each: panel kernel input (two, alternating) / output
+    float *prn;         // kMaxW x kMaxW per matrix: the normalised pivot rows of the current sub-panel
     float *gk;        // the block's panel G transposed, bw x np: A operand of the rank-bw update
     size_t gkstride;  // floats per matrix in gk
     int *submap, *rowsrc[2], *orig, *invp;  // rowsrc is double-buffered across blocks (look-ahead)
@@ -120,10 +122,14 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
     off += mbytes * batch;
     if (o) o->m1 = (float *)(c + off);
     off += mbytes * batch;
-    if (o) o->pt = (float *)(c + off);
+    if (o) o->pt[0] = (float *)(c + off);
+    off += tbytes * batch;
+    if (o) o->pt[1] = (float *)(c + off);
     off += tbytes * batch;
     if (o) o->gt = (float *)(c + off);
     off += tbytes * batch;
+    if (o) o->prn = (float *)(c + off);
+    off += align256((size_t)kMaxW * kMaxW * sizeof(float) * batch);
     const size_t gkbytes = align256((size_t)(p.bw < kMaxBW ? p.bw : kMaxBW) * p.np * sizeof(float));
     if (o) { o->gk = (float *)(c + off); o->gkstride = gkbytes / sizeof(float); }
     off += gkbytes * batch;
@@ -146,7 +152,8 @@ size_t blocked_workspace_bytes(const BlockedPlan &p, int batch) { return blocked
 __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restrict__ in, int n, int np, int ld,
                                                             size_t mstride, float *__restrict__ m0,
                                                             float *__restrict__ pt_all, size_t tstride, int w,
-                                                            int *__restrict__ orig, int *__restrict__ status)
+                                                            int *__restrict__ orig, int *__restrict__ submap,
+                                                            int *__restrict__ status)
 {
     const int b = blockIdx.z;
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -166,7 +173,10 @@ __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restri
             if (j < w) pt[(size_t)j * np + i] = v;
         }
     }
-    if (blockIdx.y == 0 && j < np) orig[(size_t)b * np + j] = j;
+    if (blockIdx.y == 0 && j < np) {
+        orig[(size_t)b * np + j] = j;
+        submap[(size_t)b * np + j] = j;  // the panel kernels only ever rewrite the positions at or below their block
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status) status[b] = MI32_OK;
 }
 
@@ -232,9 +242,8 @@ template <int NW, int W>
 struct __attribute__((aligned(16))) PanelShared {
     float cand[NW][W];          // per wave: its best candidate row as found (wave-private scratch)
     float prn[2][NW][W];        // per step parity, per wave: that row NORMALISED (candidate pivot row)
-    float piv[2][NW];           // per step parity, per wave: the candidate's pivot entry
     unsigned long long key[W];  // one cross-wave arg-max word per step, zeroed at kernel start
-    int hold[W];                // which register row (as panel_row index) holds position c0 + r
+    float prn_all[W][W];        // the normalised pivot row of every step, exported for the rows above the block
 };
 
 // which matrix row register row k of thread tid holds: V consecutive rows per thread so that the
@@ -246,104 +255,70 @@ __device__ __forceinline__ int panel_row(int tid, int k)
     return (k / V) * (V * NT) + V * tid + (k % V);
 }
 
-// inverse of panel_row: the (thread, k) that keeps matrix row `row` of the source panel
-template <int NT, int RPT>
-__device__ __forceinline__ void panel_owner(int row, int &tid, int &k)
-{
-    constexpr int V = RPT < 4 ? RPT : 4;
-    const int g = row / (V * NT);
-    const int rem = row - g * (V * NT);
-    tid = rem / V;
-    k = g * V + (rem % V);
-}
-
-// One pivot step (column c0 + r of the working matrix) with ONE workgroup barrier.
+// One pivot step (column c0 + R of the working matrix, R a compile-time constant) with ONE workgroup
+// barrier.
 //
-// With so few waves on the CU the step is latency bound, not FMA bound (s_memtime stamps,
-// tools/panel_probe.hip: the 64-128 FMAs of a step take ~150 cycles, a barrier ~300, every LDS round
-// trip ~130, a taken branch into cold code ~80).  Hence:
-//  * every wave SPECULATES: it finds its own best candidate (DPP max, one ballot), normalises that row
-//    -- the identical arithmetic the winner needs: the row divided by its own pivot-column entry, 1/piv
-//    in the identity slot -- and publishes it together with its 64-bit arg-max key.  After the single
-//    barrier the key's low bits name the winning wave and its already-normalised row is read straight
-//    from LDS: no second barrier, no division on the post-barrier path, and the winning wave already
-//    knows which of its lanes/rows held the pivot;
-//  * the step body is the SAME code for every step thanks to a ROTATION: the FMA of column c writes its
-//    result into register c-1, so the pivot column is always register 0 and after W steps every column
-//    is back in its own register; every index into the register slab is a compile-time constant
-//    (indexing the slab with the runtime step counter sends hipcc to scratch or copy-heavy code).
-//    The caller unrolls the W steps: measured 33 us per launch unrolled vs 37 us as a rolled loop --
-//    instruction fetch is not what limits this kernel, its chain of dependent LDS round trips,
-//    DPP stages, one IEEE division and the barrier is (~2 us per pivot step).
-template <int NT, int RPT, int W>
-__device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], PanelShared<NT / 64, W> &sh, int tid,
-                                           int nrows, int n, int c0, int r, bool wave_active,
+// The step is a chain of dependent, mostly scalar and cross-lane operations executed by in-order waves:
+// s_memtime stamps (tools/panel_probe.hip) show ~3500 cycles per step even with ONE wave per SIMD, of
+// which the 16 FMAs per row are ~5 %.  What a step costs is the NUMBER of instructions every wave runs
+// between two barriers, so the step is written to be short rather than clever:
+//  * ONE pass over the lane's rows finds its best candidate under the exact order of the reference's scan
+//    (largest |a|, lowest position among equals; mat_inv_32.cpp:121-127): a 64-bit comparison of
+//    {bits(|a|), ~position}.  The whole state of a row is ONE register npl[k]: ~position (top bit set)
+//    while the row can still be chosen, its position itself (top bit clear) once it cannot -- rows above
+//    the block, rows already used as a pivot in this panel, rows beyond the matrix.  A dead row's |a| key
+//    is masked to 0 and its small npl loses every tie against a live row;
+//  * one DPP max over the 32-bit |a| keys, one ballot; only a genuine tie between lanes pays for a second
+//    DPP reduction over the positions;
+//  * every wave SPECULATES: the lane that holds the wave's best candidate writes that row to LDS, lanes
+//    0..W-1 divide one element each by the candidate's pivot-column entry (IEEE division, the identity
+//    column's entry becomes 1/pivot) and publish the NORMALISED row next to a 64-bit arg-max key
+//    (ds_max_u64).  After the single barrier the key's low bits name the winning wave and its row is read
+//    straight from LDS: no second barrier and no division on the post-barrier path;
+//  * pivotElements (mat_inv_32.cpp:154-173) is an exchange of two position labels, done branch-free by
+//    every lane (no table of who holds which position);
+//  * a NaN is never special-cased in the search: its bit pattern wins the unsigned max, the step then has
+//    a NaN pivot and the winning wave flags the matrix as singular -- the result is poisoned either way.
+template <int NT, int RPT, int W, int R>
+__device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[RPT], PanelShared<NT / 64, W> &sh,
+                                           int lane, int wave_u, int c0, bool wave_active,
                                            bool &singular MI32_STAMP_PARAM)
 {
-    const int par = r & 1;
-    const int lane = tid & 63;
-    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slot = c0 + r;
-    // a real column may only take its pivot from the real rows: the identity padding must never be
-    // swapped into the matrix (it would be, on an all-zero/NaN column, where every candidate ties at 0)
-    const unsigned span = (unsigned)((slot < n ? n : nrows) - slot);
+    constexpr int par = R & 1;
+    const int slot = c0 + R;
 
-    // -- maxPivot: positions >= slot, largest |a|, lowest position among equals, NaN never wins.
-    //    |a| >= 0, so its bit pattern orders like the value: integer max/min on the bits.
-    //    A wave all of whose rows sit above the block (position < c0) can never hold a candidate and
-    //    its labels never change: it skips the whole search with one scalar branch.
-    MI32_STAMP(r, 0);
+    // -- maxPivot over this lane's rows
+    MI32_STAMP(R, 0);
     float col[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) col[k] = a[k][0];  // the pivot column is always register 0
+    for (int k = 0; k < RPT; ++k) col[k] = a[k][R];
     int own_lane = -1, own_k = 0;
-#ifdef MI32_ABL_NO_SEARCH
-    if (wave_active && tid == 12345) {
-#else
     if (wave_active) {
-#endif
-        // candidate key of register row k: bits of |a| if the row is a valid candidate, else 0.  It is
-        // recomputed in the second pass rather than kept: 2*RPT fewer live registers, which is what
-        // lets the RPT = 16 instance (N = 16384) fit the 128-VGPR budget of 1024 threads.
-        auto cand_key = [&](int k, bool &ok) -> unsigned {
-            const float v = __builtin_fabsf(col[k]);
-            ok = ((unsigned)(pos[k] - slot) < span) && (v == v);
-            return ok ? __float_as_uint(v) : 0u;
-        };
-        unsigned bm = 0u;
+        unsigned mkey = 0u, mnp = 0u;
+        int kb = 0;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            bool ok;
-            const unsigned mk = cand_key(k, ok);
-            bm = mk > bm ? mk : bm;
+            const unsigned lm = (unsigned)((int)npl[k] >> 31);                    // all ones while live
+            const unsigned key = __float_as_uint(col[k]) & lm & 0x7fffffffu;
+            const bool better = (((unsigned long long)key << 32) | npl[k]) > (((unsigned long long)mkey << 32) | mnp);
+            mkey = better ? key : mkey;
+            mnp = better ? npl[k] : mnp;
+            kb = better ? k : kb;
         }
-        MI32_STAMP(r, 1);
-#ifdef MI32_ABL_NO_DPP
-        const unsigned wm = (unsigned)__builtin_amdgcn_readlane((int)bm, 5);
-#else
-        const unsigned wm = wave_max_u32(bm);
-#endif
-        unsigned bi = 0x7fffffffu;
-        int kb = 0;  // which of this lane's rows is its candidate
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            bool ok;
-            const unsigned mk = cand_key(k, ok);
-            const unsigned c = (ok && mk == wm) ? (unsigned)pos[k] : 0x7fffffffu;
-            const bool take = c < bi;
-            bi = take ? c : bi;
-            kb = take ? k : kb;
-        }
-        // lowest position among the lanes that hold the wave maximum: almost always exactly one lane,
-        // which one ballot + v_readlane settle; only a genuine tie pays for a second DPP reduction
-        const unsigned long long tied = __ballot(bi != 0x7fffffffu);
-        MI32_STAMP(r, 2);
-        if (tied != 0ull) {  // this wave has a candidate
-            unsigned long long one = tied;
-            if ((tied & (tied - 1ull)) != 0ull) one = __ballot(bi == wave_min_u32(bi));
-            own_lane = __ffsll((long long)one) - 1;
-            const unsigned wi = (unsigned)__builtin_amdgcn_readlane((int)bi, own_lane);
+        MI32_STAMP(R, 1);
+        const unsigned wm = wave_max_u32(mkey);
+        // lanes that hold the wave maximum and a real candidate: almost always exactly one
+        unsigned long long hit = __ballot(mkey == wm && (int)mnp < 0);
+        MI32_STAMP(R, 2);
+        if (hit != 0ull) {  // this wave has a candidate
+            if ((hit & (hit - 1ull)) != 0ull) {  // tie between lanes: lowest position = largest ~position
+                const unsigned hv = (mkey == wm && (int)mnp < 0) ? mnp : 0u;
+                const unsigned hmax = wave_max_u32(hv);  // all lanes take part: never under a lane condition
+                hit = __ballot(hv == hmax);              // hmax != 0: at least two lanes hold a live candidate
+            }
+            own_lane = __ffsll((long long)hit) - 1;
             own_k = __builtin_amdgcn_readlane(kb, own_lane);
+            const unsigned wi = ~(unsigned)__builtin_amdgcn_readlane((int)mnp, own_lane);
             // the candidate row, as found, into this wave's scratch slot (the holder lane writes it)
 #pragma unroll
             for (int k = 0; k < RPT; ++k)
@@ -356,102 +331,88 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], int (&pos)[RPT], 
                     }
                 }
             // fixRow, speculatively: lanes 0..W-1 divide one element each (IEEE); identity entry -> 1/piv.
-            // The holder lane of this same wave wrote sh.cand just above: one wave's LDS operations
-            // execute in order, so no s_barrier is needed -- only the compiler must not reorder here.
+            // One wave's LDS operations execute in order, so no s_barrier is needed between the holder
+            // lane's store and these loads -- only the compiler must not reorder here.
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const float cpiv = sh.cand[wave_u][0];
-            const float num = (lane < W) ? ((lane == 0) ? 1.0f : sh.cand[wave_u][lane]) : 0.0f;
-#ifdef MI32_ABL_NO_DIV
-            const float qv = num * cpiv;
-#else
+            const float cpiv = sh.cand[wave_u][R];
+            const float num = (lane < W) ? ((lane == R) ? 1.0f : sh.cand[wave_u][lane]) : 0.0f;
             const float qv = num / cpiv;
-#endif
             if (lane < W) sh.prn[par][wave_u][lane] = qv;
-            if (lane == 0) {
-                sh.piv[par][wave_u] = cpiv;
-                atomicMax(&sh.key[r], ((unsigned long long)wm << 32) |
+            if (lane == 0)
+                atomicMax(&sh.key[R], ((unsigned long long)wm << 32) |
                                           (unsigned long long)(((0xFFFFFu - wi) << 8) | (unsigned)wave_u));
-            }
         }
     }
-    MI32_STAMP(r, 3);
-#ifndef MI32_ABL_NO_BARRIER
+    MI32_STAMP(R, 3);
     __syncthreads();
-#endif
-    MI32_STAMP(r, 4);
-    const unsigned long long key = sh.key[r];
-    const int hs = sh.hold[r];  // the register row that currently holds position `slot`
-    const unsigned lo = (unsigned)(key & 0xFFFFFFFFull);
-    const bool none = (key == 0ull);  // no valid candidate anywhere (all-NaN column): keep the slot, flag it
-    const int p = none ? slot : (int)(0xFFFFFu - (lo >> 8));
-    const int wv = none ? -1 : (int)(lo & 0xFFu);
-    float prn[W];  // prn[0] = 1/piv (the identity column's entry), prn[c] = normalised pivot row
-    if (none) {
+    MI32_STAMP(R, 4);
+    const unsigned long long key = sh.key[R];
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(key & 0xFFFFFFFFull));
+    const int p = (int)(0xFFFFFu - (lo >> 8));
+    const int wv = (int)(lo & 0xFFu);
+    if (key == 0ull) singular = true;  // cannot happen (position `slot` is always a live candidate); never trust it
+    float prn[W];  // prn[R] = 1/piv (the identity column's entry), prn[c] = normalised pivot row
 #pragma unroll
-        for (int c = 0; c < W; ++c) prn[c] = __builtin_nanf("");
-        singular = true;
-    } else {
-#pragma unroll
-        for (int c = 0; c < W; c += 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(&sh.prn[par][wv][c]);
-            prn[c] = t.x; prn[c + 1] = t.y; prn[c + 2] = t.z; prn[c + 3] = t.w;
-        }
-        const float piv = sh.piv[par][wv];
-        if (piv == 0.0f || piv != piv) singular = true;
+    for (int c = 0; c < W; c += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(&sh.prn[par][wv][c]);
+        prn[c] = t.x; prn[c + 1] = t.y; prn[c + 2] = t.z; prn[c + 3] = t.w;
     }
 
-    MI32_STAMP(r, 5);
-    // -- fixColumn on the slab, branch-free, rotating left by one register: column c lands in register
-    //    c-1; the pivot column (register 0, the implicit identity column: entry 0 in every other row)
-    //    lands in register W-1.  The pivot row itself is overwritten right after.
-#ifdef MI32_ABL_NO_FMA
-    if (tid == 12345)
-#endif
+    MI32_STAMP(R, 5);
+    // -- fixColumn on the slab, branch-free; the pivot column holds the implicit identity column, whose
+    //    entry is 0 in every row but the pivot row.  The pivot row itself is overwritten right after.
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const float f = col[k];
 #pragma unroll
-        for (int c = 1; c < W; ++c) a[k][c - 1] = __builtin_fmaf(-f, prn[c], a[k][c]);
-        a[k][W - 1] = __builtin_fmaf(-f, prn[0], 0.0f);
+        for (int c = 0; c < W; ++c)
+            a[k][c] = (c == R) ? __builtin_fmaf(-f, prn[R], 0.0f) : __builtin_fmaf(-f, prn[c], a[k][c]);
     }
-    MI32_STAMP(r, 6);
-    // -- pivot row := normalised pivot row (same rotation), and pivotElements == exchange of two
-    //    position labels.  Only two register rows of the whole block are concerned: the winner's
-    //    candidate row (its wave knows lane and row) takes label `slot`; the row that held `slot` takes p.
+    MI32_STAMP(R, 6);
+    // -- pivotElements == exchange of two position labels: the row that held `slot` takes p ...
+    if (p != slot) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) npl[k] = (npl[k] == ~(unsigned)slot) ? ~(unsigned)p : npl[k];
+    }
+    // ... and the winner's candidate row (its wave knows lane and row) becomes the pivot row: normalised
+    // values, label `slot`, no longer a candidate
     if (wave_u == wv) {
+        // this wave's scratch slot still holds the winning row as found: its pivot entry decides "singular"
+        const float cpiv = sh.cand[wave_u][R];
+        if (cpiv == 0.0f || cpiv != cpiv) singular = true;
+        if (lane < W) sh.prn_all[R][lane] = sh.prn[par][wv][lane];
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (own_k == k) {
                 if (lane == own_lane) {
 #pragma unroll
-                    for (int c = 1; c < W; ++c) a[k][c - 1] = prn[c];
-                    a[k][W - 1] = prn[0];
-                    pos[k] = slot;
+                    for (int c = 0; c < W; ++c) a[k][c] = prn[c];
+                    npl[k] = (unsigned)slot;
                 }
             }
     }
-    if (p != slot) {
-        int ht, hk;
-        panel_owner<NT, RPT>(hs, ht, hk);
-        if ((ht >> 6) == wave_u) {
-#pragma unroll
-            for (int k = 0; k < RPT; ++k)
-                if (hk == k) {
-                    if (lane == (ht & 63)) pos[k] = p;
-                }
-        }
-        // position p is a later slot of this panel?  then that slot is now held by the row that held `slot`
-        if (tid == 0 && p < c0 + W) sh.hold[p - c0] = hs;
-    }
-    MI32_STAMP(r, 7);
+    MI32_STAMP(R, 7);
 }
 
+template <int NT, int RPT, int W, int... Rs>
+__device__ __forceinline__ void panel_steps(float (&a)[RPT][W], unsigned (&npl)[RPT], PanelShared<NT / 64, W> &sh,
+                                            int lane, int wave_u, int c0, bool wave_active,
+                                            bool &singular MI32_STAMP_PARAM, std::integer_sequence<int, Rs...>)
+{
+    (panel_step<NT, RPT, W, Rs>(a, npl, sh, lane, wave_u, c0, wave_active, singular MI32_STAMP_ARG), ...);
+}
+
+// Handles the rows [row_lo, np) of the sub-panel -- the rows that can still be chosen as pivots (row_lo = c0).
+// The rows above the block never take part in a search and never move: their part of G_s follows from the
+// W normalised pivot rows alone, which this kernel exports (prn_out) and the in-block update kernel applies
+// with the same fmaf sequence (gj_rank_update_kernel, COMPACT_G).
 template <int NT, int RPT, int W>
 __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ pt_all, float *__restrict__ gt_all,
-                                                       int np, int n, size_t tstride, int c0,
+                                                       int np, int n, size_t tstride, int c0, int row_lo,
                                                        int *__restrict__ submap_all, int *__restrict__ rowsrc_all,
                                                        int *__restrict__ orig_all, int first_in_block,
+                                                       float *__restrict__ prn_out_all,
                                                        int *__restrict__ status MI32_STAMP_PARAM)
 {
     constexpr int V = RPT < 4 ? RPT : 4;
@@ -459,18 +420,17 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ 
     __shared__ PanelShared<NT / 64, W> sh;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *pt = pt_all + (size_t)b * tstride;
     float *gt = gt_all + (size_t)b * tstride;
-    if (tid < W) {
-        sh.key[tid] = 0ull;
-        sh.hold[tid] = c0 + tid;  // no swap yet: position c0 + r sits in register row c0 + r
-    }
+    if (tid < W) sh.key[tid] = 0ull;
 
     float a[RPT][W];
-    int pos[RPT];
+    unsigned npl[RPT];
 #pragma unroll
     for (int g = 0; g < RPT / V; ++g) {
-        const int row = panel_row<NT, RPT>(tid, g * V);  // first of V consecutive rows
+        const int row = row_lo + panel_row<NT, RPT>(tid, g * V);  // first of V consecutive rows
 #pragma unroll
         for (int c = 0; c < W; ++c) {
             vecV v;
@@ -480,8 +440,14 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ 
             for (int j = 0; j < V; ++j) a[g * V + j][c] = v[j];
         }
 #pragma unroll
-        for (int j = 0; j < V; ++j)  // rows beyond the matrix get a label no step can match
-            pos[g * V + j] = (row + j < np) ? row + j : 0x40000000 + row + j;
+        for (int j = 0; j < V; ++j) {
+            const int r = row + j;
+            // A candidate is a row of the matrix at or below the block.  A real column (slot < n) may only take
+            // its pivot from the real rows: the identity padding holds exact zeros there, which can tie only
+            // with an all-zero column, and then the lowest position -- a real row -- wins the tie.
+            // Rows beyond the matrix (r >= np) are dead and are never written back.
+            npl[g * V + j] = (r >= c0 && r < np) ? ~(unsigned)r : (unsigned)r;
+        }
     }
     // the row maps this kernel will permute: fetched now, so their latency hides behind the steps,
     // and parked in thread-private LDS slots (the 1024-thread instances have no registers to spare)
@@ -491,24 +457,32 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ 
     extern __shared__ int s_park[];  // [2][RPT][NT]
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int row = panel_row<NT, RPT>(tid, k);
+        const int row = row_lo + panel_row<NT, RPT>(tid, k);
         s_park[k * NT + tid] = (first_in_block || row >= np) ? row : rowsrc[row];  // composite map so far
         s_park[(RPT + k) * NT + tid] = row < np ? orig[row] : 0;
     }
+    // rows above the block keep their place: identity entries in the maps the update kernels read
+    if (first_in_block)
+        for (int i = tid; i < row_lo; i += NT) rowsrc[i] = i;
+    if (tid < W && c0 >= W) submap[c0 - W + tid] = c0 - W + tid;  // the positions the previous sub-panel retired
     bool singular = false;
     __syncthreads();  // sh.key[] zeroed before any wave's first atomicMax; all map reads issued
     // a wave takes part in the pivot search only if at least one of its rows lies in or below the block
     const int wave_last_tid = (__builtin_amdgcn_readfirstlane(tid) | 63);
-    const bool wave_active = panel_row<NT, RPT>(wave_last_tid, RPT - 1) >= c0;
+    const bool wave_active = row_lo + panel_row<NT, RPT>(wave_last_tid, RPT - 1) >= c0;
+    panel_steps<NT, RPT, W>(a, npl, sh, lane, wave_u, c0, wave_active, singular MI32_STAMP_ARG,
+                            std::make_integer_sequence<int, W>{});
+    int pos[RPT];  // final position of every register row
 #pragma unroll
-    for (int r = 0; r < W; ++r)
-        panel_step<NT, RPT, W>(a, pos, sh, tid, np, n, c0, r, wave_active, singular MI32_STAMP_ARG);
-    // W rotations by one register: every column is back in its own register
+    for (int k = 0; k < RPT; ++k) pos[k] = (int)(npl[k] ^ (unsigned)((int)npl[k] >> 31));
 
+    // -- the W normalised pivot rows, for the rows above the block
+    __syncthreads();
+    for (int i = tid; i < W * W; i += NT) prn_out_all[(size_t)b * (kMaxW * kMaxW) + i] = sh.prn_all[i / W][i % W];
     // -- G_s, compact and by register row (coalesced); the row maps, by position
 #pragma unroll
     for (int g = 0; g < RPT / V; ++g) {
-        const int row = panel_row<NT, RPT>(tid, g * V);
+        const int row = row_lo + panel_row<NT, RPT>(tid, g * V);
         if (row < np) {
 #pragma unroll
             for (int c = 0; c < W; ++c) {
@@ -526,12 +500,36 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ 
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        if (panel_row<NT, RPT>(tid, k) < np) {
+        if (row_lo + panel_row<NT, RPT>(tid, k) < np) {
             rowsrc[pos[k]] = s_park[k * NT + tid];
             orig[pos[k]] = s_park[(RPT + k) * NT + tid];
         }
     }
-    if (singular && tid == 0 && status) status[b] = MI32_SINGULAR;
+    // only the wave that won a step has looked at that step's pivot: any wave may raise the flag
+    if (singular && lane == 0 && status) status[b] = MI32_SINGULAR;
+}
+
+// One pivot step of a row that is not a candidate, for the in-block update kernel: the row's BK panel entries
+// are spread over the 4 threads of a quad (BK/4 consecutive columns each); its current entry in column R
+// lives in thread R / (BK/4) and is broadcast with one quad_perm DPP move.
+template <int BK, int R>
+__device__ __forceinline__ void above_rows_step(float (&v)[BK / 4], const float *s_prn, int q4)
+{
+    constexpr int CPT = BK / 4;
+    constexpr int kQuad = (R / CPT) * 0x55;  // quad_perm:[q,q,q,q]
+    const float f = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[R % CPT]), kQuad, 0xf, 0xf, false));
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = q4 * CPT + j;
+        const float base = (c == R) ? 0.0f : v[j];
+        v[j] = __builtin_fmaf(-f, s_prn[R * BK + c], base);
+    }
+}
+template <int BK, int... Rs>
+__device__ __forceinline__ void above_rows_steps(float (&v)[BK / 4], const float *s_prn, int q4,
+                                                 std::integer_sequence<int, Rs...>)
+{
+    (above_rows_step<BK, Rs>(v, s_prn, q4), ...);
 }
 
 // ---- rank-k update on the fp32 matrix cores ------------------------------------
@@ -558,7 +556,8 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
                                                               int col_lo, const int *__restrict__ map_all,
                                                               int copy_panel, float *__restrict__ pt_out_all,
                                                               size_t tstride, int pt_col, int pt_w, int skip_lo,
-                                                              int skip_hi)
+                                                              int skip_hi, const float *__restrict__ pt_in_all,
+                                                              const float *__restrict__ prn_all, int above_hi)
 {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -568,6 +567,7 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     __shared__ float s_a[BK * LDA];
     __shared__ __attribute__((aligned(16))) float s_b[BK * LDB];
     __shared__ int s_map[BM];
+    __shared__ __attribute__((aligned(16))) float s_prn[COMPACT_G ? BK * BK : 4];  // the sub-panel's normalised pivot rows
 
     const int b = blockIdx.z;
     const int tid = threadIdx.x;
@@ -596,6 +596,10 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     }
 
     for (int i = tid; i < BM; i += 256) s_map[i] = map[row0 + i];
+    if constexpr (COMPACT_G) {
+        if (row0 < above_hi)  // some of this tile's rows lie above the block: their G_s is computed here
+            for (int i = tid; i < BK * BK; i += 256) s_prn[i] = prn_all[(size_t)b * (kMaxW * kMaxW) + i];
+    }
     __syncthreads();
 
     // accumulators start from the (row-mapped) old values; rows of the block start from 0
@@ -624,15 +628,28 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
 
     for (int kt = 0; kt < kdim; kt += BK) {
         if constexpr (COMPACT_G) {
-            // stage A from the compact panel: gt[k][map[row]] -- already [k][row]
+            // stage A = G_s, [k][row]; 4 threads per row, BK/4 columns each (kdim == BK, kt == 0).
+            //  * rows at or below the block: the panel kernel's compact output gt[k][map[row]];
+            //  * rows above the block (never candidates, never moved): the panel kernel did not touch them.
+            //    Their G_s is the row's W entries pt_in[k][row] taken through the W pivot steps with the
+            //    exported normalised pivot rows -- fixColumn (mat_inv_32.cpp:28-38) on one row, the very
+            //    fmaf sequence the panel kernel applies to a row that is not a candidate.
+            static_assert(BM * 4 == 256 && BK % 4 == 0, "4 threads per row");
+            constexpr int CPT = BK / 4;
+            const int rr = tid >> 2, q4 = tid & 3;
+            const int grow = row0 + rr;
+            float v[CPT];
+            if (grow >= above_hi) {
 #pragma unroll
-            for (int q = 0; q < (BM * BK + 255) / 256; ++q) {
-                const int idx = tid + q * 256;
-                if (idx < BM * BK) {
-                    const int kk = idx / BM, rr = idx % BM;
-                    s_a[kk * LDA + rr] = g[(size_t)(kt + kk) * np + s_map[rr]];
-                }
+                for (int j = 0; j < CPT; ++j) v[j] = g[(size_t)(q4 * CPT + j) * np + s_map[rr]];
+            } else {
+                const float *pt_in = pt_in_all + (size_t)b * tstride;
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) v[j] = pt_in[(size_t)(q4 * CPT + j) * np + grow];
+                above_rows_steps<BK>(v, s_prn, q4, std::make_integer_sequence<int, BK>{});
             }
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) s_a[(q4 * CPT + j) * LDA + rr] = v[j];
         } else {
             // stage A: BM x BK of the row-major panel, transposed
 #pragma unroll
@@ -740,21 +757,33 @@ __global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *
 
 #ifndef MI32_STAMPS
 template <int NT, int RPT, int W>
-static void launch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int first, int *rowsrc, int batch,
+static void launch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int sub, int *rowsrc, int batch,
                          int *d_status, hipStream_t stream)
 {
-    hipLaunchKernelGGL((gj_panel_kernel<NT, RPT, W>), dim3(batch), dim3(NT), 2 * RPT * NT * sizeof(int), stream, ws.pt,
-                       ws.gt, p.np, p.n, ws.tstride, c0, ws.submap, rowsrc, ws.orig, first, d_status);
+    hipLaunchKernelGGL((gj_panel_kernel<NT, RPT, W>), dim3(batch), dim3(NT), 2 * RPT * NT * sizeof(int), stream,
+                       ws.pt[sub & 1], ws.gt, p.np, p.n, ws.tstride, c0, c0, ws.submap, rowsrc, ws.orig, sub == 0,
+                       ws.prn, d_status);
 }
 
-static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int first, int *rowsrc, int batch,
+// The panel kernel handles the np - c0 rows at or below the block: the smallest thread geometry that holds
+// them (fewer waves and fewer rows per lane both shorten a pivot step).
+static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int sub, int *rowsrc, int batch,
                            int *d_status, hipStream_t stream)
 {
-#define MI32_PANEL_CASE(T, R, WW)                                                    \
-    if (p.nthreads_panel == T && p.rpt == R && p.w == WW) {                          \
-        launch_panel<T, R, WW>(p, ws, c0, first, rowsrc, batch, d_status, stream);   \
-        return true;                                                                 \
+    const int nrows = p.np - c0;
+    int nt, rpt = 1;
+    if (nrows <= 256) nt = 256;
+    else if (nrows <= 512) nt = 512;
+    else {
+        nt = p.nthreads_panel;
+        while (rpt * nt < nrows) rpt *= 2;
     }
+#define MI32_PANEL_CASE(T, R, WW)                                                  \
+    if (nt == T && rpt == R && p.w == WW) {                                        \
+        launch_panel<T, R, WW>(p, ws, c0, sub, rowsrc, batch, d_status, stream);   \
+        return true;                                                               \
+    }
+    MI32_PANEL_CASE(256, 1, 32) MI32_PANEL_CASE(256, 1, 16) MI32_PANEL_CASE(256, 1, 8) MI32_PANEL_CASE(256, 1, 4)
     MI32_PANEL_CASE(512, 1, 32) MI32_PANEL_CASE(512, 2, 32) MI32_PANEL_CASE(512, 4, 32) MI32_PANEL_CASE(1024, 1, 32)
     MI32_PANEL_CASE(1024, 2, 32)
     MI32_PANEL_CASE(512, 1, 16) MI32_PANEL_CASE(512, 2, 16) MI32_PANEL_CASE(512, 4, 16) MI32_PANEL_CASE(512, 8, 16)
@@ -771,14 +800,16 @@ static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, in
 // in-block update: columns [C0, C0+kb) of the block, K = w, G_s from the compact panel; exports the
 // next sub-panel's columns (if it lies in this block) into pt
 static void launch_inner_update(const BlockedPlan &p, const BlockedWs &ws, const float *x, float *y, int c0, int C0,
-                                int kb, int batch, hipStream_t stream)
+                                int kb, int sub, int batch, hipStream_t stream)
 {
     const dim3 grid(kb / 64, p.np / 64, batch);
     const int next = c0 + p.w;
     const int pt_col = (next < C0 + kb) ? next : -(1 << 30);
+    // reads sub-panel `sub`'s input panel (rows above the block) and writes the next one's: two buffers
 #define MI32_INNER(BKV)                                                                                             \
     hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, BKV, true>), grid, dim3(256), 0, stream, x, y, ws.gt,          \
-                       ws.tstride, p.np, p.ld, ws.mstride, c0, BKV, C0, ws.submap, 0, ws.pt, ws.tstride, pt_col, p.w, 0, 0)
+                       ws.tstride, p.np, p.ld, ws.mstride, c0, BKV, C0, ws.submap, 0, ws.pt[(sub + 1) & 1], ws.tstride, \
+                       pt_col, p.w, 0, 0, ws.pt[sub & 1], ws.prn, c0)
     if (p.w == 32) MI32_INNER(32);
     else if (p.w == 16) MI32_INNER(16);
     else if (p.w == 8) MI32_INNER(8);
@@ -805,7 +836,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     {
         ProfScope ps(prof, KC_INIT, stream);
         hipLaunchKernelGGL(blocked_init_kernel, dim3((np + 255) / 256, (np + 15) / 16, batch), dim3(256), 0, stream,
-                           d_a, p.n, np, p.ld, ws.mstride, ws.m0, ws.pt, ws.tstride, p.w, ws.orig, d_status);
+                           d_a, p.n, np, p.ld, ws.mstride, ws.m0, ws.pt[0], ws.tstride, p.w, ws.orig, ws.submap, d_status);
     }
     if (lookahead) {  // whatever still runs on the second stream from an earlier call shares this workspace
         if ((e = hipEventRecord(ex.events[0], ex.aux)) != hipSuccess) return e;
@@ -839,11 +870,11 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
             const int c0 = C0 + s * p.w;
             {
                 ProfScope ps(prof, KC_PANEL, stream);
-                if (!dispatch_panel(p, ws, c0, s == 0, rowsrc, batch, d_status, stream)) return hipErrorInvalidValue;
+                if (!dispatch_panel(p, ws, c0, s, rowsrc, batch, d_status, stream)) return hipErrorInvalidValue;
             }
             {
                 ProfScope ps(prof, KC_UPDATE_IN, stream);
-                launch_inner_update(p, ws, x, y, c0, C0, kb, batch, stream);
+                launch_inner_update(p, ws, x, y, c0, C0, kb, s, batch, stream);
             }
             float *t = x; x = y; y = t;
         }
@@ -869,7 +900,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                     // small tiles: only kb_next columns, so 64x64 gives 4x the workgroups of 128x128
                     hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 32, false>), dim3(kb_next / 64, np / 64, batch),
                                        dim3(256), 0, stream, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, next,
-                                       rowsrc, copy, ws.pt, ws.tstride, pt_col, p.w, 0, 0);
+                                       rowsrc, copy, ws.pt[0], ws.tstride, pt_col, p.w, 0, 0, nullptr, nullptr, 0);
                 }
                 // (B): everything else, on the second stream, after this block's panel phase
                 ev = (ev + 1) % (ex.n_events / 2);
@@ -882,7 +913,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                     // that one CU holds at most one of them -> the remaining CUs stay free for the main stream
                     hipLaunchKernelGGL((gj_rank_bw2_persistent_kernel<MI32_BW_BK>), dim3(ex.aux_workgroups, batch),
                                        dim3(256), lds_persistent, ex.aux, cur, oth, x, ws.mstride, ws.gk, ws.gkstride, np,
-                                       p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt, ws.tstride, -(1 << 30), p.w, next,
+                                       p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt[0], ws.tstride, -(1 << 30), p.w, next,
                                        next + kb_next);
                 }
                 if ((e = hipEventRecord(ex.events[ev], ex.aux)) != hipSuccess) return e;
@@ -891,8 +922,8 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 ProfScope ps(prof, KC_UPDATE_OUT, stream);
                 hipLaunchKernelGGL((gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS>), dim3((np / 128) * (np / 128), batch),
                                    dim3(256), rank_bw2_lds_bytes<MI32_BW_BK>(kb), stream, cur, oth, x, ws.mstride, ws.gk,
-                                   ws.gkstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt, ws.tstride, pt_col, p.w,
-                                   0, 0);
+                                   ws.gkstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt[0], ws.tstride, pt_col,
+                                   p.w, 0, 0);
             }
             float *t = cur; cur = oth; oth = t;
         } else {
