@@ -253,7 +253,9 @@ def main():
             "workload": ("C1 (BASELINE configs[1]): single 4096x4096 fp32 inversion per GPU per step"
                          if (n == 4096 and batch == 1) else
                          f"batch of {batch} independent {n}x{n} fp32 matrices per GPU per step"),
-            "n": n, "batch_per_gpu": batch, "algo": algo_name, "blocking": list(inv.resolved_blocking(n, batch)), "distribution": "D_gate (row-permuted U(-1,1)+sqrt(N) I)",
+            "n": n, "batch_per_gpu": batch, "algo": algo_name, "blocking": list(inv.resolved_blocking(n, batch)),
+            "panel_width_per_block": (inv.resolved_panel_widths(n, batch) if algo_id == g.ALGO_BLOCKED else None),
+            "distribution": "D_gate (row-permuted U(-1,1)+sqrt(N) I)",
             "parallelism": "independent matrices sharded over ranks, no data-path collective",
             "vs_baseline_denominator": "0.342 matrices/s: reference kernel loop, N=4096, RX 5700 (BASELINE.md)",
         },

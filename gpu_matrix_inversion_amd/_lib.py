@@ -45,6 +45,7 @@ C_ABI_SYMBOLS = (
     "mi32_last_timing",
     "mi32_resolve_algo",
     "mi32_resolve_blocking",
+    "mi32_resolve_panel_widths",
     "mi32_dominant_kernel",
     "mi32_last_error",
     "mi32_version",
@@ -125,6 +126,8 @@ def load() -> ctypes.CDLL:
     lib.mi32_resolve_algo.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.mi32_resolve_blocking.restype = ctypes.c_int
     lib.mi32_resolve_blocking.argtypes = [vp, ctypes.c_int, ctypes.c_int, ip, ip]
+    lib.mi32_resolve_panel_widths.restype = ctypes.c_int
+    lib.mi32_resolve_panel_widths.argtypes = [vp, ctypes.c_int, ctypes.c_int, ip, ctypes.c_int, ip]
     lib.mi32_dominant_kernel.restype = ctypes.c_char_p
     lib.mi32_dominant_kernel.argtypes = [ctypes.c_int]
     lib.mi32_last_error.restype = ctypes.c_char_p

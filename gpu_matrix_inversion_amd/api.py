@@ -141,6 +141,14 @@ class Inverter:
                    "mi32_resolve_blocking")
         return w.value, bw.value
 
+    def resolved_panel_widths(self, n: int, batch: int = 1):
+        """Sub-panel width of every outer block (narrow while many rows are still candidates)."""
+        nb = ctypes.c_int()
+        buf = (ctypes.c_int * 128)()
+        _lib.check(self._lib.mi32_resolve_panel_widths(self._h, int(n), int(batch), buf, 128, ctypes.byref(nb)),
+                   "mi32_resolve_panel_widths")
+        return [int(buf[i]) for i in range(min(nb.value, 128))]
+
     def dominant_kernel(self, n: int, batch: int = 1) -> str:
         return self._lib.mi32_dominant_kernel(self.resolved_algo(n, batch)).decode()
 

@@ -61,9 +61,21 @@ static constexpr int kMaxBW = 512;  // widest outer block (rows of the transpose
 
 static constexpr int kMaxW = 32;  // widest sub-panel (columns kept in registers)
 
-// Panel-kernel geometry: NT threads hold np rows x w columns in registers, rpt rows each.
-// 1024 threads (4 waves/SIMD, <= 128 VGPRs) halve every wave's per-step row work, which is what
-// the step latency is made of; below np = 2048 there are not enough rows to fill them.
+// Panel-kernel geometry: NT threads hold the rows at or below the block x w columns in registers, rpt rows
+// each (1024 threads leave <= 128 VGPRs per lane, i.e. rpt * w <= 64 floats of slab).
+// Thread geometry of a panel launch that holds `nrows` rows: the smallest that fits (fewer waves and fewer
+// rows per lane both shorten a pivot step).
+static void panel_geometry(const BlockedPlan &p, int nrows, int &nt, int &rpt)
+{
+    rpt = 1;
+    if (nrows <= 256) nt = 256;
+    else if (nrows <= 512) nt = 512;
+    else {
+        nt = p.nthreads_panel;
+        while (rpt * nt < nrows) rpt *= 2;
+    }
+}
+
 BlockedPlan make_blocked_plan(int n, int w, int bw)
 {
     BlockedPlan p;
@@ -85,17 +97,24 @@ BlockedPlan make_blocked_plan(int n, int w, int bw)
     }
     p.nthreads_panel = nt;
     p.rpt = rpt;
-    int wmax = ((nt == 1024) ? 64 : 128) / rpt;  // floats of slab per thread
-    if (wmax > kMaxW) wmax = kMaxW;
-    if (w <= 0) w = 16;  // 32 fits for N <= 2048 and is selectable, but measured slower (4.6 vs 4.2 ms at 2048^2)
-    if (w > wmax) w = wmax;
+    if (w <= 0) w = 16;  // 32 is selectable where it fits, but measured slower (4.6 vs 4.2 ms at 2048^2)
     w = (w >= 32) ? 32 : (w >= 16) ? 16 : (w >= 8 ? 8 : 4);
-    p.w = w;  // wmax < 4 (np > 16384) is rejected by blocked_supported()
+    p.w = w;
     if (bw <= 0) bw = 256;
     bw = (bw + 127) & ~127;
-    if (bw > 512) bw = 512;
+    if (bw > kMaxBW) bw = kMaxBW;
     if (bw > p.np) bw = p.np;
     p.bw = bw;
+    p.nblk = (p.np + bw - 1) / bw;
+    for (int b = 0; b < p.nblk && b < 128; ++b) {
+        int bnt, brpt;
+        panel_geometry(p, p.np - b * bw, bnt, brpt);
+        int wmax = ((bnt == 1024) ? 64 : 128) / brpt;  // floats of slab per thread
+        if (wmax > kMaxW) wmax = kMaxW;
+        int wb = w < wmax ? w : wmax;                  // wmax < 4 (np > 16384) is rejected by blocked_supported()
+        wb = (wb >= 32) ? 32 : (wb >= 16) ? 16 : (wb >= 8 ? 8 : 4);
+        p.wblk[b] = (unsigned char)wb;
+    }
     return p;
 }
 bool blocked_supported(int n) { return n > 0 && ((n + 127) & ~127) <= 16384; }
@@ -464,7 +483,8 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ 
     // rows above the block keep their place: identity entries in the maps the update kernels read
     if (first_in_block)
         for (int i = tid; i < row_lo; i += NT) rowsrc[i] = i;
-    if (tid < W && c0 >= W) submap[c0 - W + tid] = c0 - W + tid;  // the positions the previous sub-panel retired
+    // the positions the previous sub-panel retired (at most kMaxW of them; identity is right for every earlier one)
+    if (tid < kMaxW && c0 - kMaxW + tid >= 0) submap[c0 - kMaxW + tid] = c0 - kMaxW + tid;
     bool singular = false;
     __syncthreads();  // sh.key[] zeroed before any wave's first atomicMax; all map reads issued
     // a wave takes part in the pivot search only if at least one of its rows lies in or below the block
@@ -767,19 +787,13 @@ static void launch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int 
 
 // The panel kernel handles the np - c0 rows at or below the block: the smallest thread geometry that holds
 // them (fewer waves and fewer rows per lane both shorten a pivot step).
-static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int sub, int *rowsrc, int batch,
+static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int w, int c0, int sub, int *rowsrc, int batch,
                            int *d_status, hipStream_t stream)
 {
-    const int nrows = p.np - c0;
-    int nt, rpt = 1;
-    if (nrows <= 256) nt = 256;
-    else if (nrows <= 512) nt = 512;
-    else {
-        nt = p.nthreads_panel;
-        while (rpt * nt < nrows) rpt *= 2;
-    }
+    int nt, rpt;
+    panel_geometry(p, p.np - c0, nt, rpt);
 #define MI32_PANEL_CASE(T, R, WW)                                                  \
-    if (nt == T && rpt == R && p.w == WW) {                                        \
+    if (nt == T && rpt == R && w == WW) {                                          \
         launch_panel<T, R, WW>(p, ws, c0, sub, rowsrc, batch, d_status, stream);   \
         return true;                                                               \
     }
@@ -799,20 +813,20 @@ static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, in
 
 // in-block update: columns [C0, C0+kb) of the block, K = w, G_s from the compact panel; exports the
 // next sub-panel's columns (if it lies in this block) into pt
-static void launch_inner_update(const BlockedPlan &p, const BlockedWs &ws, const float *x, float *y, int c0, int C0,
-                                int kb, int sub, int batch, hipStream_t stream)
+static void launch_inner_update(const BlockedPlan &p, const BlockedWs &ws, int w, const float *x, float *y, int c0,
+                                int C0, int kb, int sub, int batch, hipStream_t stream)
 {
     const dim3 grid(kb / 64, p.np / 64, batch);
-    const int next = c0 + p.w;
+    const int next = c0 + w;
     const int pt_col = (next < C0 + kb) ? next : -(1 << 30);
     // reads sub-panel `sub`'s input panel (rows above the block) and writes the next one's: two buffers
 #define MI32_INNER(BKV)                                                                                             \
     hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, BKV, true>), grid, dim3(256), 0, stream, x, y, ws.gt,          \
                        ws.tstride, p.np, p.ld, ws.mstride, c0, BKV, C0, ws.submap, 0, ws.pt[(sub + 1) & 1], ws.tstride, \
-                       pt_col, p.w, 0, 0, ws.pt[sub & 1], ws.prn, c0)
-    if (p.w == 32) MI32_INNER(32);
-    else if (p.w == 16) MI32_INNER(16);
-    else if (p.w == 8) MI32_INNER(8);
+                       pt_col, w, 0, 0, ws.pt[sub & 1], ws.prn, c0)
+    if (w == 32) MI32_INNER(32);
+    else if (w == 16) MI32_INNER(16);
+    else if (w == 8) MI32_INNER(8);
     else MI32_INNER(4);
 #undef MI32_INNER
 }
@@ -836,7 +850,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     {
         ProfScope ps(prof, KC_INIT, stream);
         hipLaunchKernelGGL(blocked_init_kernel, dim3((np + 255) / 256, (np + 15) / 16, batch), dim3(256), 0, stream,
-                           d_a, p.n, np, p.ld, ws.mstride, ws.m0, ws.pt[0], ws.tstride, p.w, ws.orig, ws.submap, d_status);
+                           d_a, p.n, np, p.ld, ws.mstride, ws.m0, ws.pt[0], ws.tstride, p.wblk[0], ws.orig, ws.submap, d_status);
     }
     if (lookahead) {  // whatever still runs on the second stream from an earlier call shares this workspace
         if ((e = hipEventRecord(ex.events[0], ex.aux)) != hipSuccess) return e;
@@ -865,16 +879,18 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     for (int C0 = 0; C0 < np; C0 += p.bw, ++blk) {
         const int kb = (C0 + p.bw <= np) ? p.bw : np - C0;
         int *rowsrc = ws.rowsrc[blk & 1];
+        const int w = p.wblk[blk];                                       // sub-panel width of this block
+        const int w_next = (blk + 1 < p.nblk) ? p.wblk[blk + 1] : w;     // ... and of the next one
         float *x = cur, *y = oth;  // the block's panel columns alternate between the two copies
-        for (int s = 0; s * p.w < kb; ++s) {
-            const int c0 = C0 + s * p.w;
+        for (int s = 0; s * w < kb; ++s) {
+            const int c0 = C0 + s * w;
             {
                 ProfScope ps(prof, KC_PANEL, stream);
-                if (!dispatch_panel(p, ws, c0, s, rowsrc, batch, d_status, stream)) return hipErrorInvalidValue;
+                if (!dispatch_panel(p, ws, w, c0, s, rowsrc, batch, d_status, stream)) return hipErrorInvalidValue;
             }
             {
                 ProfScope ps(prof, KC_UPDATE_IN, stream);
-                launch_inner_update(p, ws, x, y, c0, C0, kb, s, batch, stream);
+                launch_inner_update(p, ws, w, x, y, c0, C0, kb, s, batch, stream);
             }
             float *t = x; x = y; y = t;
         }
@@ -900,7 +916,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                     // small tiles: only kb_next columns, so 64x64 gives 4x the workgroups of 128x128
                     hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 32, false>), dim3(kb_next / 64, np / 64, batch),
                                        dim3(256), 0, stream, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, next,
-                                       rowsrc, copy, ws.pt[0], ws.tstride, pt_col, p.w, 0, 0, nullptr, nullptr, 0);
+                                       rowsrc, copy, ws.pt[0], ws.tstride, pt_col, w_next, 0, 0, nullptr, nullptr, 0);
                 }
                 // (B): everything else, on the second stream, after this block's panel phase
                 ev = (ev + 1) % (ex.n_events / 2);
@@ -913,7 +929,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                     // that one CU holds at most one of them -> the remaining CUs stay free for the main stream
                     hipLaunchKernelGGL((gj_rank_bw2_persistent_kernel<MI32_BW_BK>), dim3(ex.aux_workgroups, batch),
                                        dim3(256), lds_persistent, ex.aux, cur, oth, x, ws.mstride, ws.gk, ws.gkstride, np,
-                                       p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt[0], ws.tstride, -(1 << 30), p.w, next,
+                                       p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt[0], ws.tstride, -(1 << 30), w_next, next,
                                        next + kb_next);
                 }
                 if ((e = hipEventRecord(ex.events[ev], ex.aux)) != hipSuccess) return e;
@@ -923,7 +939,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 hipLaunchKernelGGL((gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS>), dim3((np / 128) * (np / 128), batch),
                                    dim3(256), rank_bw2_lds_bytes<MI32_BW_BK>(kb), stream, cur, oth, x, ws.mstride, ws.gk,
                                    ws.gkstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt[0], ws.tstride, pt_col,
-                                   p.w, 0, 0);
+                                   w_next, 0, 0);
             }
             float *t = cur; cur = oth; oth = t;
         } else {

@@ -280,6 +280,15 @@ int mi32_resolve_blocking(mi32_handle_t h, int n, int batch, int *panel_width, i
     return MI32_OK;
 }
 
+int mi32_resolve_panel_widths(mi32_handle_t h, int n, int batch, int *widths, int capacity, int *nblocks)
+{
+    if (n <= 0 || batch <= 0 || capacity < 0 || (capacity > 0 && !widths)) return MI32_BAD_SHAPE;
+    const BlockedPlan p = plan_blocked(h, n, batch);
+    if (nblocks) *nblocks = p.nblk;
+    for (int b = 0; b < p.nblk && b < capacity; ++b) widths[b] = p.wblk[b];
+    return MI32_OK;
+}
+
 const char *mi32_dominant_kernel(int algo)
 {
     return algo == MI32_ALGO_SWEEP ? "gj_sweep_step_kernel" : "gj_rank_bw2_kernel";

@@ -73,10 +73,15 @@ struct BlockedPlan {
     int n;     // matrix order
     int np;    // padded order (multiple of 128), identity padding
     int ld;    // row stride of the working copies in floats (np + 64)
-    int w;     // sub-panel width
+    int w;     // widest sub-panel allowed (what the caller asked for; 16 by default)
     int bw;    // outer block width
     int nthreads_panel;
-    int rpt;   // rows per thread in the panel kernel
+    int rpt;   // rows per thread in the panel kernel when it holds all np rows
+    // Sub-panel width of every outer block.  The panel kernel keeps (rows at or below the block) x width
+    // floats in registers, so the first blocks of a large matrix use narrow sub-panels and the width grows
+    // as the elimination retires rows (16384 rows: 4, 8192: 8, 4096 and fewer: 16).
+    int nblk;
+    unsigned char wblk[128];
 };
 
 SweepPlan make_sweep_plan(int n);

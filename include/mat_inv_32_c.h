@@ -109,8 +109,12 @@ int mi32_get_profile(mi32_handle_t h, double *ms_per_class, long long *launches_
 int mi32_last_timing(double *total_seconds, double *compute_seconds);
 /* which algorithm a call of this shape would use after AUTO resolution */
 int mi32_resolve_algo(mi32_handle_t h, int n, int batch);
-/* sub-panel and outer block width the blocked path would use for this shape */
+/* widest sub-panel allowed and outer block width the blocked path would use for this shape */
 int mi32_resolve_blocking(mi32_handle_t h, int n, int batch, int *panel_width, int *block_width);
+/* The sub-panel width of every outer block (the panel kernel keeps rows x width floats in registers, so the
+ * first blocks of a large matrix use narrower sub-panels): *nblocks receives the number of outer blocks,
+ * widths[0 .. min(capacity, *nblocks)) their sub-panel widths. */
+int mi32_resolve_panel_widths(mi32_handle_t h, int n, int batch, int *widths, int capacity, int *nblocks);
 /* name of the dominant device kernel of that algorithm (for rocprof filtering) */
 const char *mi32_dominant_kernel(int algo);
 /* thread-local description of the last MI32_RUNTIME_ERROR */

@@ -387,16 +387,16 @@ static void rank_update(float *m, size_t ld, int n, int r0, int kw, int j_lo, in
     }
 }
 
-int gjo_matrix_inv_32_blocked2(const float *in, size_t in_len, int n, float *out, int w, int bw, int *pivots)
+int gjo_matrix_inv_32_blocked2w(const float *in, size_t in_len, int n, float *out, const int *w_of_block, int nblocks,
+                                int bw, int *pivots)
 {
     if (!shape_ok(in_len, n)) return GJO_BAD_SHAPE;
-    if (w <= 0) w = 16;
-    if (bw < w) bw = w;
+    if (!w_of_block || nblocks <= 0 || bw <= 0) return GJO_BAD_SHAPE;
     const size_t ld = (size_t)n;
     float *m = (float *)malloc(sizeof(float) * ld * n);
     int *orig = (int *)malloc(sizeof(int) * n);
     float *rs = (float *)malloc(sizeof(float) * (size_t)bw * n);
-    float *prn = (float *)malloc(sizeof(float) * w);
+    float *prn = (float *)malloc(sizeof(float) * 64);
     if (!m || !orig || !rs || !prn) {
         free(m); free(orig); free(rs); free(prn);
         return GJO_BAD_SHAPE;
@@ -405,8 +405,12 @@ int gjo_matrix_inv_32_blocked2(const float *in, size_t in_len, int n, float *out
     for (int i = 0; i < n; ++i) orig[i] = i;
     int status = GJO_OK;
 
-    for (int C0 = 0; C0 < n; C0 += bw) {
+    int blk = 0;
+    for (int C0 = 0; C0 < n; C0 += bw, ++blk) {
         const int kb = (C0 + bw <= n) ? bw : n - C0;
+        int w = w_of_block[blk < nblocks ? blk : nblocks - 1]; /* sub-panel width of this outer block */
+        if (w <= 0) w = 16;
+        if (w > 64) w = 64;
         for (int c0 = C0; c0 < C0 + kb; c0 += w) {
             const int kw = (c0 + w <= C0 + kb) ? w : C0 + kb - c0;
             for (int s = 0; s < kw; ++s) {
@@ -443,6 +447,13 @@ int gjo_matrix_inv_32_blocked2(const float *in, size_t in_len, int n, float *out
         for (int c = 0; c < n; ++c) out[(size_t)i * n + orig[c]] = m[(size_t)i * ld + c];
     free(m); free(orig); free(rs); free(prn);
     return status;
+}
+
+int gjo_matrix_inv_32_blocked2(const float *in, size_t in_len, int n, float *out, int w, int bw, int *pivots)
+{
+    if (w <= 0) w = 16;
+    if (bw < w) bw = w;
+    return gjo_matrix_inv_32_blocked2w(in, in_len, n, out, &w, 1, bw, pivots);
 }
 
 /* ---- metrics ----------------------------------------------------------- */

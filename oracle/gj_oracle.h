@@ -81,6 +81,10 @@ int gjo_matrix_inv_32_blocked(const float *in, size_t in_len, int n, float *out,
  * (sub-panels of w inside outer blocks of bw): bit-identical to it. */
 int gjo_matrix_inv_32_blocked2(const float *in, size_t in_len, int n, float *out,
                                int w, int bw, int *pivots);
+/* The same with one sub-panel width per outer block (w_of_block[b], the last entry repeated if there are more
+ * blocks): the HIP path widens its sub-panels as the elimination retires rows (mi32_resolve_panel_widths). */
+int gjo_matrix_inv_32_blocked2w(const float *in, size_t in_len, int n, float *out, const int *w_of_block,
+                                int nblocks, int bw, int *pivots);
 
 /* ||A*X - I||_inf (max abs row sum), product accumulated in double. */
 double gjo_residual_inf(const float *a, const float *x, int n);

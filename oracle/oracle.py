@@ -65,6 +65,8 @@ def _load():
     lib.gjo_matrix_inv_32_blocked.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ctypes.c_int, ip]
     lib.gjo_matrix_inv_32_blocked2.restype = ctypes.c_int
     lib.gjo_matrix_inv_32_blocked2.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, ip]
+    lib.gjo_matrix_inv_32_blocked2w.restype = ctypes.c_int
+    lib.gjo_matrix_inv_32_blocked2w.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ip, ctypes.c_int, ctypes.c_int, ip]
     for nm in ("gjo_residual_inf", "gjo_residual_inf_left", "gjo_frobenius_metric"):
         getattr(lib, nm).restype = ctypes.c_double
         getattr(lib, nm).argtypes = [fp, fp, ctypes.c_int]
@@ -140,8 +142,9 @@ def matrix_inv_32_blocked(vec, n: int, w: int = 16, return_info: bool = False):
     return out
 
 
-def matrix_inv_32_blocked2(vec, n: int, w: int = 16, bw: int = 256, return_info: bool = False):
-    """Exact CPU mirror of the HIP blocked path's block structure (sub-panels w, outer blocks bw)."""
+def matrix_inv_32_blocked2(vec, n: int, w=16, bw: int = 256, return_info: bool = False):
+    """Exact CPU mirror of the HIP blocked path's block structure (sub-panels w, outer blocks bw).
+    w: one width, or a sequence with the sub-panel width of every outer block."""
     lib = _load()
     v = _f32(vec)
     n = int(n)
@@ -150,8 +153,14 @@ def matrix_inv_32_blocked2(vec, n: int, w: int = 16, bw: int = 256, return_info:
         return (empty, {"status": STATUS_BAD_SHAPE}) if return_info else empty
     out = np.empty(n * n, dtype=np.float32)
     piv = np.empty(n, dtype=np.int32)
-    st = lib.gjo_matrix_inv_32_blocked2(_fp(v), v.size, n, _fp(out), int(w), int(bw),
-                                        piv.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if isinstance(w, (list, tuple, np.ndarray)):
+        ws = np.ascontiguousarray(w, dtype=np.int32)
+        st = lib.gjo_matrix_inv_32_blocked2w(_fp(v), v.size, n, _fp(out),
+                                             ws.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), int(ws.size), int(bw),
+                                             piv.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    else:
+        st = lib.gjo_matrix_inv_32_blocked2(_fp(v), v.size, n, _fp(out), int(w), int(bw),
+                                            piv.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
     if return_info:
         return out, {"status": st, "pivots": piv}
     return out

@@ -82,8 +82,8 @@ def test_blocked_bit_identical_to_blocked_mirror(oracle, inv_blocked, n):
         if kind == "hollow" and n == 1:
             continue
         a = dist_matrix(kind, n, 8000 + n)
-        w, bw = inv_blocked.resolved_blocking(n, 1)
-        want = oracle.matrix_inv_32_blocked2(a, n, w, bw)
+        _, bw = inv_blocked.resolved_blocking(n, 1)
+        want = oracle.matrix_inv_32_blocked2(a, n, inv_blocked.resolved_panel_widths(n, 1), bw)
         got, st = run(inv_blocked, a)
         assert st[0] == 0
         assert np.array_equal(got.reshape(-1), want), (kind, n, np.abs(got.reshape(-1) - want).max())
@@ -95,7 +95,8 @@ def test_blocked_other_blockings(oracle, w, bw):
     try:
         for n in (200, 640):
             a = dist_matrix("gate", n, 8100 + n + w)
-            want = oracle.matrix_inv_32_blocked2(a, n, w, bw)
+            assert inv.resolved_blocking(n, 1) == (w, bw if bw <= ((n + 127) & ~127) else ((n + 127) & ~127))
+            want = oracle.matrix_inv_32_blocked2(a, n, inv.resolved_panel_widths(n, 1), bw)
             got, st = run(inv, a)
             assert st[0] == 0
             assert np.array_equal(got.reshape(-1), want), (w, bw, n)
@@ -182,7 +183,8 @@ def test_batched_with_a_singular_member(oracle, inv_sweep, inv_blocked):
     mats = np.stack([gate_matrix(n, 900 + b) for b in range(B)])
     mats[3] = 1.0  # rank-1: singular
     for inv, mirror in ((inv_sweep, lambda m: oracle.matrix_inv_32(m, n)),
-                        (inv_blocked, lambda m: oracle.matrix_inv_32_blocked2(m, n, *inv_blocked.resolved_blocking(n, B)))):
+                        (inv_blocked, lambda m: oracle.matrix_inv_32_blocked2(m, n, inv_blocked.resolved_panel_widths(n, B),
+                                                                               inv_blocked.resolved_blocking(n, B)[1]))):
         got, st = run(inv, mats)
         assert list(st) == [0, 0, 0, 2, 0, 0]
         for b in range(B):
@@ -271,14 +273,16 @@ def test_c1_single_4096_sweep_and_blocked_agree(inv_sweep, inv_blocked):
     assert rel < 1e-5, rel
 
 
-def test_blocked_4200_w8_instance_bit_identical_to_mirror(oracle, inv_blocked):
-    """N = 4200 pads to 4224 rows: 1024 threads x 8 rows, which only fits W = 8 columns in registers."""
+def test_blocked_4200_width_schedule_bit_identical_to_mirror(oracle, inv_blocked):
+    """N = 4200 pads to 4224 rows: while more than 4096 rows are candidates the panel kernel holds 8 rows
+    per lane and only W = 8 columns fit in registers; from the second outer block on W = 16."""
     n = 4200
     a = gate_matrix(n, 40_000)
     w, bw = inv_blocked.resolved_blocking(n, 1)
-    assert (w, bw) == (8, 256)
+    widths = inv_blocked.resolved_panel_widths(n, 1)
+    assert (w, bw) == (16, 256) and widths[0] == 8 and set(widths[1:]) == {16} and len(widths) == 17
     got, st = run(inv_blocked, a)
-    want = oracle.matrix_inv_32_blocked2(a, n, w, bw)
+    want = oracle.matrix_inv_32_blocked2(a, n, widths, bw)
     assert st[0] == 0 and np.array_equal(got.reshape(-1), want)
 
 
