@@ -6,19 +6,24 @@
 // column updates of a block of pivots delayed:
 //
 //   for each outer block K = [C0, C0+kb) of pivot columns:
-//     for each sub-panel Ks = [c0, c0+W) of K:
-//       gj_panel_kernel     -- ONE workgroup per matrix holds all rows of the W
-//                              sub-panel columns in registers and runs the W
-//                              pivot steps on them: column arg-max (DPP + one LDS
-//                              atomic), row swap (= exchange of two position
-//                              labels), IEEE-division normalise, eliminate.
-//                              Result: G_s = the W transformed columns (the
-//                              inverse columns of these pivots).
-//       gj_rank_update_kernel (K = W)  -- every other column j of the block:
-//                              M[i][j] = (i in Ks ? 0 : M[src(i)][j])
-//                                        + sum_k G_s[i][k] * M[src(c0+k)][j]
-//     gj_rank_update_kernel (K = kb)   -- every column outside the block, same
-//                              formula with the block's composite G and row map.
+//     for each sub-panel s, Ks = [c0, c0+W) of K:
+//       panel(s)   -- ONE workgroup per matrix holds the rows that can still be
+//                     chosen as pivots, W columns each, in registers and runs the W
+//                     pivot steps on them: column arg-max (DPP + one LDS atomic), row
+//                     swap (= exchange of two position labels), IEEE-division
+//                     normalise, eliminate.  Result: G_s = the W transformed columns
+//                     (the inverse columns of these pivots).
+//       update(s)  -- every other column j of the block (fp32 MFMA, K = W):
+//                     M[i][j] = (i in Ks ? 0 : M[src(i)][j]) + sum_k G_s[i][k] * M[src(c0+k)][j]
+//     rank-bw update (K = kb, mi32_rank_bw.h) -- every column outside the block, same
+//                     formula with the block's composite G and row map.
+//
+// panel(s) and update(s-1) are ONE launch (gj_subpanel_kernel: workgroup 0 of a
+// matrix is the panel, the others are update tiles): update(s-1) no longer sits
+// between two panels on the critical path of the N pivot steps.  What panel(s)
+// needs from update(s-1) -- its own W columns -- it computes itself in a prologue
+// (the same k-ascending fmaf chain the MFMA update runs), from the panel input
+// that update(s-2) exported one launch earlier.
 //
 // Row swaps are never applied as data movement of their own: the updates read
 // their C rows and their B (pivot-row) operand THROUGH a row map and write
@@ -27,14 +32,19 @@
 // The two working copies alternate roles exactly like the reference's
 // ping-pong buffers (mat_inv_32.cpp:318,353-360).
 //
-// The panel kernel is a single workgroup on the critical path of all N pivot
-// steps, so it only ever touches COMPACT, TRANSPOSED panels: it reads
-// Pt[c][row] (W x np, written by whichever wide kernel produced those columns)
-// and writes Gt[c][row], both with fully coalesced 16-byte accesses.  The wide
-// update kernels, which hold those values anyway, export the next sub-panel's
-// columns into Pt and materialise G_s into the row-major matrix.  (Letting the
-// one workgroup gather 64-byte chunks of np rows itself cost 18 us per launch,
-// more than its 16 pivot steps.)
+// The panel workgroup only ever touches COMPACT, TRANSPOSED panels: it reads
+// Pt[c][row] (W x np, exported by whichever wide kernel produced those columns)
+// and writes Gt[c][row], with coalesced accesses.  (Letting the one workgroup
+// gather 64-byte chunks of np rows itself cost 18 us per launch, more than its 16
+// pivot steps.)
+//
+// Row orders.  "Order after t" = the rows arranged by the position they hold after
+// sub-panel t's swaps.  update(t) writes the working copy and its exports in order
+// after t.  panel(s) therefore receives its input Pt_s (exported by update(s-2)) in
+// order after s-2 and the previous panel's output Gt_{s-1} in that same order;
+// what it needs on top is every row's position after s-1, its label at entry
+// (invsub_{s-1}).  It writes Gt_s by those labels, i.e. in order after s-1, which
+// is the order update(s) reads the working copy in.
 //
 // The working matrix is the N x N in-place form (see mi32_sweep.hip), padded
 // with an identity block to a multiple of 128 so that no tile needs bounds
@@ -121,57 +131,67 @@ bool blocked_supported(int n) { return n > 0 && ((n + 127) & ~127) <= 16384; }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct BlockedWs {
-    float *m0, *m1;   // the two working copies, np x ld each
-    float *pt[2], *gt;  // compact transposed panels, kMaxW x np each: panel kernel input (two, alternating) / output
-    float *prn;         // kMaxW x kMaxW per matrix: the normalised pivot rows of the current sub-panel
-    float *gk;        // the block's panel G transposed, bw x np: A operand of the rank-bw update
-    size_t gkstride;  // floats per matrix in gk
-    int *submap, *rowsrc[2], *orig, *invp;  // rowsrc is double-buffered across blocks (look-ahead)
-    size_t mstride;   // floats per matrix in m0/m1
-    size_t tstride;   // floats per matrix in pt/gt
+    float *m0, *m1;     // the two working copies, np x ld each
+    float *pt[3];       // compact transposed panel inputs, kMaxW x np each: sub-panel s of a block uses pt[s % 3]
+    float *gt[2];       // compact transposed panel outputs G_s: gt[s & 1]
+    float *aux[2];      // per sub-panel: the W normalised pivot rows, and the previous sub-panel's pivot rows
+                        // restricted to this sub-panel's columns (2 x kMaxW x kMaxW floats per matrix)
+    float *gk;          // the block's panel G transposed, bw x np: A operand of the rank-bw update
+    size_t gkstride;    // floats per matrix in gk
+    int *submap[2], *invsub[2];  // per sub-panel: position after s -> index in order after s-1, and its inverse
+    int *rowsrc[2], *orig, *invp;  // rowsrc is double-buffered across blocks (look-ahead)
+    size_t mstride;     // floats per matrix in m0/m1
+    size_t tstride;     // floats per matrix in pt/gt
+    size_t pt_bstride;  // floats between pt[i] and pt[i + 1]
 };
 static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, BlockedWs *o)
 {
     const size_t mbytes = align256((size_t)p.np * p.ld * sizeof(float));
     const size_t tbytes = align256((size_t)kMaxW * p.np * sizeof(float));
     const size_t ibytes = align256((size_t)p.np * sizeof(int) * batch);
+    const size_t abytes = align256((size_t)2 * kMaxW * kMaxW * sizeof(float) * batch);
     char *c = (char *)base;
     size_t off = 0;
-    if (o) { o->m0 = (float *)(c + off); o->mstride = mbytes / sizeof(float); o->tstride = tbytes / sizeof(float); }
+    if (o) {
+        o->m0 = (float *)(c + off);
+        o->mstride = mbytes / sizeof(float);
+        o->tstride = tbytes / sizeof(float);
+        o->pt_bstride = tbytes * batch / sizeof(float);
+    }
     off += mbytes * batch;
     if (o) o->m1 = (float *)(c + off);
     off += mbytes * batch;
-    if (o) o->pt[0] = (float *)(c + off);
-    off += tbytes * batch;
-    if (o) o->pt[1] = (float *)(c + off);
-    off += tbytes * batch;
-    if (o) o->gt = (float *)(c + off);
-    off += tbytes * batch;
-    if (o) o->prn = (float *)(c + off);
-    off += align256((size_t)kMaxW * kMaxW * sizeof(float) * batch);
+    for (int i = 0; i < 3; ++i) {
+        if (o) o->pt[i] = (float *)(c + off);
+        off += tbytes * batch;
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (o) o->gt[i] = (float *)(c + off);
+        off += tbytes * batch;
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (o) o->aux[i] = (float *)(c + off);
+        off += abytes;
+    }
     const size_t gkbytes = align256((size_t)(p.bw < kMaxBW ? p.bw : kMaxBW) * p.np * sizeof(float));
     if (o) { o->gk = (float *)(c + off); o->gkstride = gkbytes / sizeof(float); }
     off += gkbytes * batch;
-    if (o) o->submap = (int *)(c + off);
-    off += ibytes;
-    if (o) o->rowsrc[0] = (int *)(c + off);
-    off += ibytes;
-    if (o) o->rowsrc[1] = (int *)(c + off);
-    off += ibytes;
-    if (o) o->orig = (int *)(c + off);
-    off += ibytes;
-    if (o) o->invp = (int *)(c + off);
-    off += ibytes;
+    int **maps[8] = {o ? &o->submap[0] : nullptr, o ? &o->submap[1] : nullptr, o ? &o->invsub[0] : nullptr,
+                     o ? &o->invsub[1] : nullptr, o ? &o->rowsrc[0] : nullptr, o ? &o->rowsrc[1] : nullptr,
+                     o ? &o->orig : nullptr,      o ? &o->invp : nullptr};
+    for (int i = 0; i < 8; ++i) {
+        if (o) *maps[i] = (int *)(c + off);
+        off += ibytes;
+    }
     return off;
 }
 size_t blocked_workspace_bytes(const BlockedPlan &p, int batch) { return blocked_carve(p, batch, nullptr, nullptr); }
 
 // ---- init: A -> diag(A, I) in the first working copy (makeAugmentedMatrix counterpart,
-//      mat_inv_32.cpp:177-192) + the compact copy of the first sub-panel's columns ---------
+//      mat_inv_32.cpp:177-192) + the compact copies of the first two sub-panels' columns ------
 __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restrict__ in, int n, int np, int ld,
-                                                            size_t mstride, float *__restrict__ m0,
-                                                            float *__restrict__ pt_all, size_t tstride, int w,
-                                                            int *__restrict__ orig, int *__restrict__ submap,
+                                                            size_t mstride, float *__restrict__ m0, PanelExport ex,
+                                                            size_t tstride, int *__restrict__ orig,
                                                             int *__restrict__ status)
 {
     const int b = blockIdx.z;
@@ -179,7 +199,6 @@ __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restri
     const int i0 = blockIdx.y * 16;
     const float *a = in + (size_t)b * n * n;
     float *m = m0 + (size_t)b * mstride;
-    float *pt = pt_all + (size_t)b * tstride;
     if (j < np) {
 #pragma unroll 4
         for (int u = 0; u < 16; ++u) {
@@ -189,13 +208,10 @@ __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restri
             if (i < n && j < n) v = a[(size_t)i * n + j];
             else v = (i == j) ? 1.0f : 0.0f;
             m[(size_t)i * ld + j] = v;
-            if (j < w) pt[(size_t)j * np + i] = v;
+            panel_export_store(ex, tstride, b, np, j, i, v);
         }
     }
-    if (blockIdx.y == 0 && j < np) {
-        orig[(size_t)b * np + j] = j;
-        submap[(size_t)b * np + j] = j;  // the panel kernels only ever rewrite the positions at or below their block
-    }
+    if (blockIdx.y == 0 && j < np) orig[(size_t)b * np + j] = j;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status) status[b] = MI32_OK;
 }
 
@@ -230,32 +246,14 @@ __device__ __forceinline__ float lane_bcast(float v, int srclane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
 }
 
-// ---- the panel: W pivot steps on an (np x W) register-resident slab -----------
+// ---- the panel: W pivot steps on a register-resident slab ----------------------
 // Each thread keeps RPT rows of the panel in registers for the whole kernel: row
 // CONTENTS never move between threads.  What a row swap changes is only an integer
-// label pos[k] = the position (row index of the working matrix) that the content of
-// register row k currently occupies:
+// label = the position (row index of the working matrix) that the content of a
+// register row currently occupies:
 //   pivotElements (mat_inv_32.cpp:154-173)  ==  exchange of two labels.
-// submap[position] = the row of the source copy X whose data now belongs at that
-// position tells the rank-k updates where every other column's data still lives.
-
-// Diagnostic builds (tools/panel_probe.hip, -DMI32_STAMPS) record s_memtime at the phase
-// boundaries of every step; in the product build the macro expands to nothing.
-#ifdef MI32_STAMPS
-#define MI32_STAMP(step, slot_)                                                           \
-    do {                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        if (stamp_buf && threadIdx.x == blockDim.x - 64 && blockIdx.x == 0)               \
-            stamp_buf[(step) * 8 + (slot_)] = __builtin_amdgcn_s_memtime();               \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-    } while (0)
-#define MI32_STAMP_PARAM , unsigned long long *stamp_buf
-#define MI32_STAMP_ARG , stamp_buf
-#else
-#define MI32_STAMP(step, slot_) do { } while (0)
-#define MI32_STAMP_PARAM
-#define MI32_STAMP_ARG
-#endif
+// submap[position] = where the data that now belongs at that position lies in the
+// previous order tells the rank-k updates where every other column's data still lives.
 
 template <int NW, int W>
 struct __attribute__((aligned(16))) PanelShared {
@@ -263,6 +261,7 @@ struct __attribute__((aligned(16))) PanelShared {
     float prn[2][NW][W];        // per step parity, per wave: that row NORMALISED (candidate pivot row)
     unsigned long long key[W];  // one cross-wave arg-max word per step, zeroed at kernel start
     float prn_all[W][W];        // the normalised pivot row of every step, exported for the rows above the block
+    float bprev[W][W];          // the previous sub-panel's W pivot rows, restricted to this sub-panel's columns
 };
 
 // which matrix row register row k of thread tid holds: V consecutive rows per thread so that the
@@ -300,14 +299,17 @@ __device__ __forceinline__ int panel_row(int tid, int k)
 //    a NaN pivot and the winning wave flags the matrix as singular -- the result is poisoned either way.
 template <int NT, int RPT, int W, int R>
 __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[RPT], PanelShared<NT / 64, W> &sh,
-                                           int lane, int wave_u, int c0, bool wave_active,
-                                           bool &singular MI32_STAMP_PARAM)
+                                           int wave_u, int c0, bool wave_active, bool &singular)
 {
     constexpr int par = R & 1;
     const int slot = c0 + R;
+    // The lane id is recomputed in every step (two v_mbcnt, opaque to the optimiser): a `lane` carried through
+    // the 16 unrolled steps is the first thing the 128-VGPR instances spill, and every path of the step reads
+    // it -- a scratch reload in front of each compare on the critical path.
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
 
     // -- maxPivot over this lane's rows
-    MI32_STAMP(R, 0);
     float col[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) col[k] = a[k][R];
@@ -324,11 +326,9 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
             mnp = better ? npl[k] : mnp;
             kb = better ? k : kb;
         }
-        MI32_STAMP(R, 1);
         const unsigned wm = wave_max_u32(mkey);
         // lanes that hold the wave maximum and a real candidate: almost always exactly one
         unsigned long long hit = __ballot(mkey == wm && (int)mnp < 0);
-        MI32_STAMP(R, 2);
         if (hit != 0ull) {  // this wave has a candidate
             if ((hit & (hit - 1ull)) != 0ull) {  // tie between lanes: lowest position = largest ~position
                 const unsigned hv = (mkey == wm && (int)mnp < 0) ? mnp : 0u;
@@ -363,9 +363,7 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
                                           (unsigned long long)(((0xFFFFFu - wi) << 8) | (unsigned)wave_u));
         }
     }
-    MI32_STAMP(R, 3);
     __syncthreads();
-    MI32_STAMP(R, 4);
     const unsigned long long key = sh.key[R];
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(key & 0xFFFFFFFFull));
     const int p = (int)(0xFFFFFu - (lo >> 8));
@@ -377,8 +375,6 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
         const float4 t = *reinterpret_cast<const float4 *>(&sh.prn[par][wv][c]);
         prn[c] = t.x; prn[c + 1] = t.y; prn[c + 2] = t.z; prn[c + 3] = t.w;
     }
-
-    MI32_STAMP(R, 5);
     // -- fixColumn on the slab, branch-free; the pivot column holds the implicit identity column, whose
     //    entry is 0 in every row but the pivot row.  The pivot row itself is overwritten right after.
 #pragma unroll
@@ -388,7 +384,6 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
         for (int c = 0; c < W; ++c)
             a[k][c] = (c == R) ? __builtin_fmaf(-f, prn[R], 0.0f) : __builtin_fmaf(-f, prn[c], a[k][c]);
     }
-    MI32_STAMP(R, 6);
     // -- pivotElements == exchange of two position labels: the row that held `slot` takes p ...
     if (p != slot) {
 #pragma unroll
@@ -411,45 +406,88 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
                 }
             }
     }
-    MI32_STAMP(R, 7);
 }
 
 template <int NT, int RPT, int W, int... Rs>
 __device__ __forceinline__ void panel_steps(float (&a)[RPT][W], unsigned (&npl)[RPT], PanelShared<NT / 64, W> &sh,
-                                            int lane, int wave_u, int c0, bool wave_active,
-                                            bool &singular MI32_STAMP_PARAM, std::integer_sequence<int, Rs...>)
+                                            int wave_u, int c0, bool wave_active, bool &singular,
+                                            std::integer_sequence<int, Rs...>)
 {
-    (panel_step<NT, RPT, W, Rs>(a, npl, sh, lane, wave_u, c0, wave_active, singular MI32_STAMP_ARG), ...);
+    (panel_step<NT, RPT, W, Rs>(a, npl, sh, wave_u, c0, wave_active, singular), ...);
 }
 
-// Handles the rows [row_lo, np) of the sub-panel -- the rows that can still be chosen as pivots (row_lo = c0).
-// The rows above the block never take part in a search and never move: their part of G_s follows from the
-// W normalised pivot rows alone, which this kernel exports (prn_out) and the in-block update kernel applies
-// with the same fmaf sequence (gj_rank_update_kernel, COMPACT_G).
-template <int NT, int RPT, int W>
-__global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ pt_all, float *__restrict__ gt_all,
-                                                       int np, int n, size_t tstride, int c0, int row_lo,
-                                                       int *__restrict__ submap_all, int *__restrict__ rowsrc_all,
-                                                       int *__restrict__ orig_all, int first_in_block,
-                                                       float *__restrict__ prn_out_all,
-                                                       int *__restrict__ status MI32_STAMP_PARAM)
+// Everything one fused sub-panel launch needs (passed by value).
+struct SubpanelArgs {
+    int np, n, ld, batch;
+    size_t mstride, tstride;
+    // ---- panel(s): workgroup b < batch of the grid (absent when panel_on == 0)
+    int panel_on;
+    int c0;        // first column of sub-panel s
+    int has_prev;  // update(s-1) is still pending on this sub-panel's columns: apply it in the prologue
+    int c0_prev;   // first column of sub-panel s-1
+    int row_lo;    // the workgroup holds the rows [row_lo, np) of its input order
+    int first_in_block;
+    const float *pt_in;      // Pt_s: this sub-panel's columns, updates up to s-2 applied, order after s-2
+    const float *gt_prev;    // Gt_{s-1}, same order
+    float *gt_out;           // Gt_s, order after s-1
+    const int *invsub_prev;  // index in order after s-2 -> position after s-1 (the row's label at entry)
+    int *submap_out;         // position after s -> index in order after s-1
+    int *invsub_out;         // its inverse
+    int *rowsrc, *orig;
+    float *aux_out;          // [2][kMaxW*kMaxW] per matrix: normalised pivot rows of s; pivot rows of s-1 x columns of s
+    int *status;
+    // ---- update(t), t = s-1: the other workgroups (absent when upd_on == 0)
+    int upd_on;
+    int u_c0;        // first column of sub-panel t
+    int u_has_prev;  // sub-panel t itself had a pending update (t >= 1 within its block)
+    int u_above_hi;  // positions below this were not in panel(t): their G_t is computed by the update tile
+    int C0, kb;      // the outer block
+    const float *x;  // working copy in order after t-1
+    float *y;        // working copy written in order after t
+    const float *u_gt;     // Gt_t
+    const int *u_submap;   // submap_t
+    const float *u_pt_in;  // Pt_t (for the rows above the block)
+    const float *u_aux;    // aux_t
+    PanelExport u_exp;     // the columns of sub-panel t+2 -> its compact panel input
+};
+
+template <int NW, int W>
+constexpr size_t panel_shared_bytes()
 {
+    return (sizeof(PanelShared<NW, W>) + 15) & ~(size_t)15;
+}
+
+// panel(s) of one matrix: the whole workgroup.  smem: panel_shared_bytes + 2 * RPT * NT ints.
+// FUSED = false compiles the pending-update prologue (and the labels-at-entry indirection) out: the instances
+// with 4 and more rows per lane have no registers to spare for code they never run.
+template <int NT, int RPT, int W, bool FUSED>
+__device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, unsigned char *smem)
+{
+    const bool has_prev = FUSED && A.has_prev;
     constexpr int V = RPT < 4 ? RPT : 4;
+    constexpr int NW = NT / 64;
     typedef float vecV __attribute__((ext_vector_type(V)));
-    __shared__ PanelShared<NT / 64, W> sh;
-    const int b = blockIdx.x;
+    typedef int ivecV __attribute__((ext_vector_type(V)));
+    PanelShared<NW, W> &sh = *reinterpret_cast<PanelShared<NW, W> *>(smem);
+    int *s_park = reinterpret_cast<int *>(smem + panel_shared_bytes<NW, W>());  // [2][RPT][NT]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float *pt = pt_all + (size_t)b * tstride;
-    float *gt = gt_all + (size_t)b * tstride;
+    const int np = A.np, c0 = A.c0, row_lo = A.row_lo;
+    const float *pt = A.pt_in + (size_t)b * A.tstride;
+    const int *invsub_prev = A.invsub_prev + (size_t)b * np;
     if (tid < W) sh.key[tid] = 0ull;
 
+    // -- the slab and every row's label at entry (its position after the previous sub-panel's swaps)
     float a[RPT][W];
     unsigned npl[RPT];
 #pragma unroll
     for (int g = 0; g < RPT / V; ++g) {
         const int row = row_lo + panel_row<NT, RPT>(tid, g * V);  // first of V consecutive rows
+        ivecV p0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) p0[j] = row + j;
+        if (has_prev && row < np) p0 = *reinterpret_cast<const ivecV *>(invsub_prev + row);
 #pragma unroll
         for (int c = 0; c < W; ++c) {
             vecV v;
@@ -460,76 +498,144 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(const float *__restrict__ 
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const int r = row + j;
             // A candidate is a row of the matrix at or below the block.  A real column (slot < n) may only take
             // its pivot from the real rows: the identity padding holds exact zeros there, which can tie only
             // with an all-zero column, and then the lowest position -- a real row -- wins the tie.
-            // Rows beyond the matrix (r >= np) are dead and are never written back.
-            npl[g * V + j] = (r >= c0 && r < np) ? ~(unsigned)r : (unsigned)r;
+            // Rows beyond the matrix (row >= np) are dead and are never written back.
+            const bool live = (row + j < np) && (p0[j] >= c0);
+            npl[g * V + j] = live ? ~(unsigned)p0[j] : (unsigned)p0[j];
         }
     }
-    // the row maps this kernel will permute: fetched now, so their latency hides behind the steps,
-    // and parked in thread-private LDS slots (the 1024-thread instances have no registers to spare)
-    int *submap = submap_all + (size_t)b * np;
-    int *rowsrc = rowsrc_all + (size_t)b * np;
-    int *orig = orig_all + (size_t)b * np;
-    extern __shared__ int s_park[];  // [2][RPT][NT]
+    // the row maps this workgroup will permute: fetched now (by label), so their latency hides behind the
+    // steps, and parked in thread-private LDS slots (the 1024-thread instances have no registers to spare)
+    int *rowsrc = A.rowsrc + (size_t)b * np;
+    int *orig = A.orig + (size_t)b * np;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int row = row_lo + panel_row<NT, RPT>(tid, k);
-        s_park[k * NT + tid] = (first_in_block || row >= np) ? row : rowsrc[row];  // composite map so far
-        s_park[(RPT + k) * NT + tid] = row < np ? orig[row] : 0;
+        const int p0 = (int)(npl[k] ^ (unsigned)((int)npl[k] >> 31));
+        s_park[k * NT + tid] = (A.first_in_block || row >= np) ? p0 : rowsrc[p0];  // composite map so far
+        s_park[(RPT + k) * NT + tid] = row < np ? orig[p0] : 0;
     }
     // rows above the block keep their place: identity entries in the maps the update kernels read
-    if (first_in_block)
+    if (A.first_in_block)
         for (int i = tid; i < row_lo; i += NT) rowsrc[i] = i;
-    // the positions the previous sub-panel retired (at most kMaxW of them; identity is right for every earlier one)
-    if (tid < kMaxW && c0 - kMaxW + tid >= 0) submap[c0 - kMaxW + tid] = c0 - kMaxW + tid;
+
+    if (has_prev) {
+        // -- update(s-1) on this sub-panel's columns, which nobody has applied yet:
+        //      a[row][c] = (row is a pivot row of s-1 ? 0 : a[row][c]) + sum_k G_{s-1}[row][k] * B[k][c],
+        //    B[k][:] = the pivot row of step k of s-1 as it stands in this panel's input, i.e. W of the rows this
+        //    workgroup holds.  One fmaf chain per element, k ascending, starting from the old value: bit for
+        //    bit what the MFMA in-block update computes for every other column.
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int rel = (int)npl[k] - A.c0_prev;  // dead rows carry their position itself
+            if ((unsigned)rel < (unsigned)W && row_lo + panel_row<NT, RPT>(tid, k) < np) {
+#pragma unroll
+                for (int c = 0; c < W; ++c) {
+                    sh.bprev[rel][c] = a[k][c];
+                    a[k][c] = 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+        const float *gtp = A.gt_prev + (size_t)b * A.tstride;
+#ifndef MI32_PRO_REGS
+#define MI32_PRO_REGS 32
+#endif
+        constexpr int KC = (MI32_PRO_REGS / RPT) < 1 ? 1 : ((MI32_PRO_REGS / RPT) > W ? W : (MI32_PRO_REGS / RPT));  // k's per round of loads
+        // a ROLLED loop over the rounds: unrolled, hipcc hoists every round's loads to the top and the whole of
+        // G_{s-1} (RPT * W registers) is live beside the slab
+#pragma unroll 1
+        for (int k0 = 0; k0 < W; k0 += KC) {
+            vecV gv[KC][RPT / V];
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                for (int g = 0; g < RPT / V; ++g) {
+                    const int row = row_lo + panel_row<NT, RPT>(tid, g * V);
+                    gv[kk][g] = (row < np) ? *reinterpret_cast<const vecV *>(gtp + (size_t)(k0 + kk) * np + row)
+                                           : (vecV)(0.0f);
+                }
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                for (int c4 = 0; c4 < W; c4 += 4) {
+                    const float4 bq = *reinterpret_cast<const float4 *>(&sh.bprev[k0 + kk][c4]);
+#pragma unroll
+                    for (int g = 0; g < RPT / V; ++g)
+#pragma unroll
+                        for (int j = 0; j < V; ++j) {
+                            const float gval = gv[kk][g][j];
+                            a[g * V + j][c4 + 0] = __builtin_fmaf(gval, bq.x, a[g * V + j][c4 + 0]);
+                            a[g * V + j][c4 + 1] = __builtin_fmaf(gval, bq.y, a[g * V + j][c4 + 1]);
+                            a[g * V + j][c4 + 2] = __builtin_fmaf(gval, bq.z, a[g * V + j][c4 + 2]);
+                            a[g * V + j][c4 + 3] = __builtin_fmaf(gval, bq.w, a[g * V + j][c4 + 3]);
+                        }
+                }
+        }
+    }
     bool singular = false;
     __syncthreads();  // sh.key[] zeroed before any wave's first atomicMax; all map reads issued
-    // a wave takes part in the pivot search only if at least one of its rows lies in or below the block
-    const int wave_last_tid = (__builtin_amdgcn_readfirstlane(tid) | 63);
-    const bool wave_active = row_lo + panel_row<NT, RPT>(wave_last_tid, RPT - 1) >= c0;
-    panel_steps<NT, RPT, W>(a, npl, sh, lane, wave_u, c0, wave_active, singular MI32_STAMP_ARG,
-                            std::make_integer_sequence<int, W>{});
+    panel_steps<NT, RPT, W>(a, npl, sh, wave_u, c0, true, singular, std::make_integer_sequence<int, W>{});
     int pos[RPT];  // final position of every register row
 #pragma unroll
     for (int k = 0; k < RPT; ++k) pos[k] = (int)(npl[k] ^ (unsigned)((int)npl[k] >> 31));
 
-    // -- the W normalised pivot rows, for the rows above the block
+    // -- for the rows above the block (update(s) computes their G_s): the W normalised pivot rows, and the
+    //    pivot rows of s-1 restricted to this sub-panel's columns
     __syncthreads();
-    for (int i = tid; i < W * W; i += NT) prn_out_all[(size_t)b * (kMaxW * kMaxW) + i] = sh.prn_all[i / W][i % W];
-    // -- G_s, compact and by register row (coalesced); the row maps, by position
+    float *aux = A.aux_out + (size_t)b * (2 * kMaxW * kMaxW);
+    for (int i = tid; i < W * W; i += NT) {
+        aux[i] = sh.prn_all[i / W][i % W];
+        if (has_prev) aux[kMaxW * kMaxW + i] = sh.bprev[i / W][i % W];
+    }
+    // -- G_s by label at entry (order after s-1: what update(s) reads the working copy in); the row maps
+    float *gt = A.gt_out + (size_t)b * A.tstride;
+    int *submap = A.submap_out + (size_t)b * np;
+    int *invsub = A.invsub_out + (size_t)b * np;
+    // positions retired since this map buffer was last written: identity (any earlier position already is)
+    if (tid < 4 * kMaxW && row_lo - 4 * kMaxW + tid >= 0) submap[row_lo - 4 * kMaxW + tid] = row_lo - 4 * kMaxW + tid;
 #pragma unroll
     for (int g = 0; g < RPT / V; ++g) {
         const int row = row_lo + panel_row<NT, RPT>(tid, g * V);
         if (row < np) {
+            ivecV p0;  // the labels at entry, again (no registers were kept for them)
 #pragma unroll
-            for (int c = 0; c < W; ++c) {
-                vecV v;
+            for (int j = 0; j < V; ++j) p0[j] = row + j;
+            if (has_prev) p0 = *reinterpret_cast<const ivecV *>(invsub_prev + row);
+            bool contiguous = (p0[0] % V) == 0;
 #pragma unroll
-                for (int j = 0; j < V; ++j) v[j] = a[g * V + j][c];
-                *reinterpret_cast<vecV *>(gt + (size_t)c * np + row) = v;
+            for (int j = 1; j < V; ++j) contiguous = contiguous && (p0[j] == p0[0] + j);
+            if (contiguous) {
+#pragma unroll
+                for (int c = 0; c < W; ++c) {
+                    vecV v;
+#pragma unroll
+                    for (int j = 0; j < V; ++j) v[j] = a[g * V + j][c];
+                    *reinterpret_cast<vecV *>(gt + (size_t)c * np + p0[0]) = v;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < W; ++c)
+#pragma unroll
+                    for (int j = 0; j < V; ++j) gt[(size_t)c * np + p0[j]] = a[g * V + j][c];
             }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const int k = g * V + j;
-                submap[pos[k]] = row + j;  // position pos[k] now holds X's row (row + j)
+                submap[pos[k]] = p0[j];  // position pos[k] now holds what lies at index p0[j] of the order after s-1
+                invsub[p0[j]] = pos[k];
+                rowsrc[pos[k]] = s_park[k * NT + tid];
+                orig[pos[k]] = s_park[(RPT + k) * NT + tid];
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        if (row_lo + panel_row<NT, RPT>(tid, k) < np) {
-            rowsrc[pos[k]] = s_park[k * NT + tid];
-            orig[pos[k]] = s_park[(RPT + k) * NT + tid];
-        }
-    }
     // only the wave that won a step has looked at that step's pivot: any wave may raise the flag
-    if (singular && lane == 0 && status) status[b] = MI32_SINGULAR;
+    if (singular && lane == 0 && A.status) A.status[b] = MI32_SINGULAR;
 }
 
-// One pivot step of a row that is not a candidate, for the in-block update kernel: the row's BK panel entries
+// One pivot step of a row that is not a candidate, for the in-block update tiles: the row's BK panel entries
 // are spread over the 4 threads of a quad (BK/4 consecutive columns each); its current entry in column R
 // lives in thread R / (BK/4) and is broadcast with one quad_perm DPP move.
 template <int BK, int R>
@@ -552,42 +658,206 @@ __device__ __forceinline__ void above_rows_steps(float (&v)[BK / 4], const float
     (above_rows_step<BK, Rs>(v, s_prn, q4), ...);
 }
 
-// ---- rank-k update on the fp32 matrix cores ------------------------------------
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+// ---- update(t): the in-block rank-W update on the fp32 matrix cores ---------------
+//   y[i][j] = (i in Ks ? 0 : x[map[i]][j]) + sum_k G_t[i][k] * x[map[c0+k]][j]
+// for the columns j of the block that are not sub-panel t's own, 64 x 64 tiles, 256 threads = 4 waves in
+// a 2x2 arrangement per tile (NG tiles per workgroup), one 32x32 MFMA tile per wave.  One accumulation
+// chain per output element, starting from the old value, k ascending: bit for bit the fmaf chain of
+// oracle/gj_oracle.c's blocked restatement.  The column-tile-0 workgroups also materialise G_t into
+// y[i][c0 + k] (row-major), where every later update expects it.
+template <int BK>
+struct __attribute__((aligned(16))) UpdateTileShared {
+    static constexpr int LDA = 64 + ((32 / BK) > 0 ? (32 / BK) : 1);
+    static constexpr int LDB = 64 + 4;
+    float s_b[BK * LDB];     // pivot rows (through the row map) x 64 columns
+    float s_prn[BK * BK];    // sub-panel t's normalised pivot rows
+    float s_bprev[BK * BK];  // sub-panel t-1's pivot rows restricted to sub-panel t's columns
+    float s_a[BK * LDA];     // G_t of the tile's rows, [k][row]
+    int s_map[64];
+};
+
+template <int BK, int NG>
+__device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u, unsigned char *smem)
+{
+    typedef UpdateTileShared<BK> TS;
+    constexpr int LDA = TS::LDA, LDB = TS::LDB;
+    constexpr int CPT = BK / 4;
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    TS &T = reinterpret_cast<TS *>(smem)[grp];
+    const int np = A.np, ld = A.ld, c0 = A.u_c0;
+    const int tiles_x = A.kb / 64;
+    const int wgs_per_matrix = tiles_x * (np / 64) / NG;
+    const int b = u / wgs_per_matrix;
+    const int id = (u % wgs_per_matrix) * NG + grp;
+    const int tx = id % tiles_x, ty = id / tiles_x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int row0 = ty * 64;
+    const int col0 = A.C0 + tx * 64;
+    const float *src = A.x + (size_t)b * A.mstride;
+    float *dst = A.y + (size_t)b * A.mstride;
+    const float *g = A.u_gt + (size_t)b * A.tstride;
+    const int *map = A.u_submap + (size_t)b * np;
+    const bool some_above = row0 < A.u_above_hi;  // some of this tile's rows were not in panel(t)
+
+    if (tid < 64) T.s_map[tid] = map[row0 + tid];
+    if (some_above) {
+        const float *aux = A.u_aux + (size_t)b * (2 * kMaxW * kMaxW);
+        for (int i = tid; i < BK * BK; i += 256) {
+            T.s_prn[i] = aux[i];
+            if (A.u_has_prev) T.s_bprev[i] = aux[kMaxW * kMaxW + i];
+        }
+    }
+    __syncthreads();
+
+    // accumulators start from the (row-mapped) old values; rows of the sub-panel's pivots start from 0
+    float16v acc;
+    const int lcol = lane & 31;
+    const int lhalf = lane >> 5;
+    {
+        const int col = col0 + wc * 32 + lcol;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lr = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+            const int grow = row0 + lr;
+            const bool in_block = (grow >= c0 && grow < c0 + BK);
+            acc[reg] = in_block ? 0.0f : src[(size_t)T.s_map[lr] * ld + col];
+        }
+    }
+    {
+        // stage A = G_t, [k][row]; 4 threads per row, BK/4 columns each.
+        //  * rows that were in panel(t): its compact output gt[k][map[row]];
+        //  * rows above (never candidates, never moved): their G_t is the row's W entries of the panel input
+        //    Pt_t, brought up to date with update(t-1) where that was still pending (the chain of the panel
+        //    prologue: old value + sum_k G_{t-1}[row][k] * Bprev[k][c], G_{t-1} as materialised in x), then
+        //    taken through the W pivot steps with the exported normalised pivot rows -- fixColumn
+        //    (mat_inv_32.cpp:28-38) on one row, the very fmaf sequence the panel applies to a dead row.
+        const int rr = tid >> 2, q4 = tid & 3;
+        const int grow = row0 + rr;
+        float v[CPT];
+        if (grow >= A.u_above_hi) {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) v[j] = g[(size_t)(q4 * CPT + j) * np + T.s_map[rr]];
+        } else {
+            const float *pt_in = A.u_pt_in + (size_t)b * A.tstride;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) v[j] = pt_in[(size_t)(q4 * CPT + j) * np + grow];
+            if (A.u_has_prev) {
+                const float *gp = src + (size_t)grow * ld + (c0 - BK);  // G_{t-1}[grow][0..BK): same width, same block
+#pragma unroll
+                for (int k4 = 0; k4 < BK; k4 += 4) {
+                    const float4 gq = *reinterpret_cast<const float4 *>(gp + k4);
+                    const float gk4[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int j = 0; j < CPT; ++j)
+                            v[j] = __builtin_fmaf(gk4[kk], T.s_bprev[(k4 + kk) * BK + q4 * CPT + j], v[j]);
+                }
+            }
+            above_rows_steps<BK>(v, T.s_prn, q4, std::make_integer_sequence<int, BK>{});
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) T.s_a[(q4 * CPT + j) * LDA + rr] = v[j];
+    }
+    // stage B: BK pivot rows (through the row map) x 64 columns
+#pragma unroll
+    for (int q = 0; q < (BK * 16 + 255) / 256; ++q) {
+        const int idx = tid + q * 256;
+        if (idx < BK * 16) {
+            const int kk = idx / 16, c4 = (idx % 16) * 4;
+            const int brow = map[c0 + kk];
+            *reinterpret_cast<float4 *>(&T.s_b[kk * LDB + c4]) =
+                *reinterpret_cast<const float4 *>(src + (size_t)brow * ld + col0 + c4);
+        }
+    }
+    __syncthreads();
+    // materialise G_t into the row-major working copy (column tile 0 only)
+    if (tx == 0) {
+        for (int idx = tid; idx < 64 * (BK / 4); idx += 256) {
+            const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+            *reinterpret_cast<float4 *>(dst + (size_t)(row0 + rr) * ld + c0 + k4) =
+                make_float4(T.s_a[(k4 + 0) * LDA + rr], T.s_a[(k4 + 1) * LDA + rr], T.s_a[(k4 + 2) * LDA + rr],
+                            T.s_a[(k4 + 3) * LDA + rr]);
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+        const float af = T.s_a[(kk + lhalf) * LDA + wr * 32 + lcol];
+        const float bf = T.s_b[(kk + lhalf) * LDB + wc * 32 + lcol];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+    }
+    {
+        const int col = col0 + wc * 32 + lcol;
+        if (!(col >= c0 && col < c0 + BK)) {  // sub-panel t's own columns hold G_t, not an update result
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int grow = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                dst[(size_t)grow * ld + col] = acc[reg];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)  // registers 4q .. 4q+3 are 4 consecutive rows: one 16-byte store
+                panel_export_store4(A.u_exp, A.tstride, b, np, col, row0 + wr * 32 + 8 * q + 4 * lhalf, acc[4 * q],
+                                    acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+    }
+}
+
+// ---- one launch per sub-panel: panel(s) || update(s-1) ------------------------------
+template <int NT, int RPT, int W, bool FUSED>
+constexpr size_t subpanel_lds_bytes()
+{
+    const size_t pb = panel_shared_bytes<NT / 64, W>() + (size_t)2 * RPT * NT * sizeof(int);
+    const size_t ub = FUSED ? sizeof(UpdateTileShared<W>) * (NT / 256) : 0;
+    return pb > ub ? pb : ub;
+}
+
+// FUSED: workgroups [0, batch) are the panels of sub-panel s, the others the update tiles of sub-panel s-1
+// (NT / 256 tiles each).  !FUSED: the panel alone.
+template <int NT, int RPT, int W, bool FUSED>
+__global__ __launch_bounds__(NT) void gj_subpanel_kernel(SubpanelArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    if constexpr (FUSED) {
+        const int npanel = A.panel_on ? A.batch : 0;
+        if ((int)blockIdx.x < npanel) panel_body<NT, RPT, W, true>(A, (int)blockIdx.x, sp_smem);
+        else inblock_update_body<W, NT / 256>(A, (int)blockIdx.x - npanel, sp_smem);
+    } else {
+        panel_body<NT, RPT, W, false>(A, (int)blockIdx.x, sp_smem);
+    }
+}
+
+// update(t) alone: one 64 x 64 tile per 256-thread workgroup
+template <int W>
+__global__ __launch_bounds__(256) void gj_inblock_update_kernel(SubpanelArgs A)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char upd_smem[sizeof(UpdateTileShared<W>)];
+    inblock_update_body<W, 1>(A, (int)blockIdx.x, upd_smem);
+}
+
+// ---- rank-k update of the next block's columns (look-ahead half (A) of a rank-bw update) -----
 //   dst[i][j] = (i in [c0,c0+kdim) ? 0 : src[map[i]][j]) + sum_k G[i][k] * src[map[c0+k]][j]
-// for the columns j of this tile that are not panel columns.  256 threads = 4
-// waves in a 2x2 arrangement; each wave owns (BM/2)x(BN/2) as 32x32 MFMA tiles.
-// A = G is staged into LDS as [k][row] so that the 32 lanes of a half-wave read 32
-// consecutive floats; B (= pivot rows, row-major) is staged as it lies.  One
-// accumulation chain per output element, k ascending: bit-for-bit the fmaf chain
-// of oracle/gj_oracle.c's blocked restatement.
-//
-// COMPACT_G (the in-block update, kdim == BK == w): G_s comes from the panel
-//   kernel's compact output gt[k][map[i]]; the column-tile-0 workgroups also
-//   materialise it into dst[i][c0 + k] (row-major), where every later update
-//   expects it.
-// !COMPACT_G (the rank-bw update): G is the block's panel, row-major in g_all.
-// Either flavour exports the columns [pt_col, pt_col + pt_w) it has just
-// computed into the compact transposed panel pt_out (the next sub-panel's input).
-template <int BM, int BN, int BK, bool COMPACT_G>
+// for the 64-column tiles starting at col_lo.  Same arithmetic as the rank-bw kernel of mi32_rank_bw.h (sum of
+// products from zero, k ascending, old value added last), on 64 x 64 tiles because the few columns of one block
+// would otherwise make too few workgroups; G is read from the row-major working copy.
+template <int BK>
 __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__restrict__ src_all,
                                                               float *__restrict__ dst_all,
                                                               const float *__restrict__ g_all, size_t gstride,
                                                               int np, int ld, size_t mstride, int c0, int kdim,
                                                               int col_lo, const int *__restrict__ map_all,
-                                                              int copy_panel, float *__restrict__ pt_out_all,
-                                                              size_t tstride, int pt_col, int pt_w, int skip_lo,
-                                                              int skip_hi, const float *__restrict__ pt_in_all,
-                                                              const float *__restrict__ prn_all, int above_hi)
+                                                              PanelExport ex, size_t tstride)
 {
-    constexpr int WM = BM / 2, WN = BN / 2;
-    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int BM = 64, BN = 64;
     constexpr int PADA = (32 / BK) > 0 ? (32 / BK) : 1;
     constexpr int LDA = BM + PADA;
     constexpr int LDB = BN + 4;
     __shared__ float s_a[BK * LDA];
     __shared__ __attribute__((aligned(16))) float s_b[BK * LDB];
     __shared__ int s_map[BM];
-    __shared__ __attribute__((aligned(16))) float s_prn[COMPACT_G ? BK * BK : 4];  // the sub-panel's normalised pivot rows
 
     const int b = blockIdx.z;
     const int tid = threadIdx.x;
@@ -600,89 +870,36 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     float *dst = dst_all + (size_t)b * mstride;
     const float *g = g_all + (size_t)b * gstride;
     const int *map = map_all + (size_t)b * np;
-    float *pt_out = pt_out_all + (size_t)b * tstride;
-
-    if (col0 >= skip_lo && col0 < skip_hi) return;  // these columns belong to the other half of a split update
-    if (!COMPACT_G && col0 >= c0 && col0 + BN <= c0 + kdim) {
-        // tile lies inside the panel: those columns are G itself
-        if (copy_panel) {
-            for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
-                const int rr = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
-                *reinterpret_cast<float4 *>(dst + (size_t)(row0 + rr) * ld + col0 + c4) =
-                    *reinterpret_cast<const float4 *>(g + (size_t)(row0 + rr) * ld + col0 + c4);
-            }
-        }
-        return;
-    }
 
     for (int i = tid; i < BM; i += 256) s_map[i] = map[row0 + i];
-    if constexpr (COMPACT_G) {
-        if (row0 < above_hi)  // some of this tile's rows lie above the block: their G_s is computed here
-            for (int i = tid; i < BK * BK; i += 256) s_prn[i] = prn_all[(size_t)b * (kMaxW * kMaxW) + i];
-    }
     __syncthreads();
 
-    // accumulators start from the (row-mapped) old values; rows of the block start from 0
-    float16v acc[TM][TN], cin[TM][TN];
+    float16v acc, cin;
     const int lcol = lane & 31;
     const int lhalf = lane >> 5;
+    {
+        const int col = col0 + wc * 32 + lcol;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = col0 + wc * WN + tn * 32 + lcol;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int lr = wr * WM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                const int grow = row0 + lr;
-                const bool in_block = (grow >= c0 && grow < c0 + kdim);
-                const float cval = in_block ? 0.0f : src[(size_t)s_map[lr] * ld + col];
-                if constexpr (COMPACT_G) {
-                    acc[tm][tn][reg] = cval;  // in-block update: the chain starts from the old value
-                } else {
-                    cin[tm][tn][reg] = cval;  // rank-bw update: sum from zero, old value added at the end
-                    acc[tm][tn][reg] = 0.0f;
-                }
-            }
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lr = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+            const int grow = row0 + lr;
+            const bool in_block = (grow >= c0 && grow < c0 + kdim);
+            cin[reg] = in_block ? 0.0f : src[(size_t)s_map[lr] * ld + col];
+            acc[reg] = 0.0f;
         }
-
+    }
     for (int kt = 0; kt < kdim; kt += BK) {
-        if constexpr (COMPACT_G) {
-            // stage A = G_s, [k][row]; 4 threads per row, BK/4 columns each (kdim == BK, kt == 0).
-            //  * rows at or below the block: the panel kernel's compact output gt[k][map[row]];
-            //  * rows above the block (never candidates, never moved): the panel kernel did not touch them.
-            //    Their G_s is the row's W entries pt_in[k][row] taken through the W pivot steps with the
-            //    exported normalised pivot rows -- fixColumn (mat_inv_32.cpp:28-38) on one row, the very
-            //    fmaf sequence the panel kernel applies to a row that is not a candidate.
-            static_assert(BM * 4 == 256 && BK % 4 == 0, "4 threads per row");
-            constexpr int CPT = BK / 4;
-            const int rr = tid >> 2, q4 = tid & 3;
-            const int grow = row0 + rr;
-            float v[CPT];
-            if (grow >= above_hi) {
+        // stage A: BM x BK of the row-major panel, transposed
 #pragma unroll
-                for (int j = 0; j < CPT; ++j) v[j] = g[(size_t)(q4 * CPT + j) * np + s_map[rr]];
-            } else {
-                const float *pt_in = pt_in_all + (size_t)b * tstride;
-#pragma unroll
-                for (int j = 0; j < CPT; ++j) v[j] = pt_in[(size_t)(q4 * CPT + j) * np + grow];
-                above_rows_steps<BK>(v, s_prn, q4, std::make_integer_sequence<int, BK>{});
-            }
-#pragma unroll
-            for (int j = 0; j < CPT; ++j) s_a[(q4 * CPT + j) * LDA + rr] = v[j];
-        } else {
-            // stage A: BM x BK of the row-major panel, transposed
-#pragma unroll
-            for (int q = 0; q < (BM * BK / 4 + 255) / 256; ++q) {
-                const int idx = tid + q * 256;
-                if (idx < BM * BK / 4) {
-                    const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                    const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)(row0 + rr) * ld + c0 + kt + k4);
-                    s_a[(k4 + 0) * LDA + rr] = v.x;
-                    s_a[(k4 + 1) * LDA + rr] = v.y;
-                    s_a[(k4 + 2) * LDA + rr] = v.z;
-                    s_a[(k4 + 3) * LDA + rr] = v.w;
-                }
+        for (int q = 0; q < (BM * BK / 4 + 255) / 256; ++q) {
+            const int idx = tid + q * 256;
+            if (idx < BM * BK / 4) {
+                const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+                const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)(row0 + rr) * ld + c0 + kt + k4);
+                s_a[(k4 + 0) * LDA + rr] = v.x;
+                s_a[(k4 + 1) * LDA + rr] = v.y;
+                s_a[(k4 + 2) * LDA + rr] = v.z;
+                s_a[(k4 + 3) * LDA + rr] = v.w;
             }
         }
         // stage B: BK pivot rows (through the row map) x BN columns
@@ -692,54 +909,33 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
             if (idx < BK * BN / 4) {
                 const int kk = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
                 const int brow = map[c0 + kt + kk];
-                const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)brow * ld + col0 + c4);
-                *reinterpret_cast<float4 *>(&s_b[kk * LDB + c4]) = v;
+                *reinterpret_cast<float4 *>(&s_b[kk * LDB + c4]) =
+                    *reinterpret_cast<const float4 *>(src + (size_t)brow * ld + col0 + c4);
             }
         }
         __syncthreads();
-        if constexpr (COMPACT_G) {
-            // materialise G_s into the row-major working copy (column tile 0 only; kdim == BK)
-            if (blockIdx.x == 0) {
-                for (int idx = tid; idx < BM * (BK / 4); idx += 256) {
-                    const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                    *reinterpret_cast<float4 *>(dst + (size_t)(row0 + rr) * ld + c0 + k4) =
-                        make_float4(s_a[(k4 + 0) * LDA + rr], s_a[(k4 + 1) * LDA + rr], s_a[(k4 + 2) * LDA + rr],
-                                    s_a[(k4 + 3) * LDA + rr]);
-                }
-            }
-        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float af[TM], bf[TN];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) af[tm] = s_a[(kk + lhalf) * LDA + wr * WM + tm * 32 + lcol];
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bf[tn] = s_b[(kk + lhalf) * LDB + wc * WN + tn * 32 + lcol];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+            const float af = s_a[(kk + lhalf) * LDA + wr * 32 + lcol];
+            const float bf = s_b[(kk + lhalf) * LDB + wc * 32 + lcol];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
         }
         __syncthreads();
     }
-
+    {
+        const int col = col0 + wc * 32 + lcol;
+        float ov[16];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = col0 + wc * WN + tn * 32 + lcol;
-            if (col >= c0 && col < c0 + kdim) continue;  // panel column: holds G, not an update result
-            const bool exp = (col >= pt_col && col < pt_col + pt_w);  // next sub-panel's column
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int grow = row0 + wr * WM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                float v = acc[tm][tn][reg];
-                if constexpr (!COMPACT_G) v += cin[tm][tn][reg];
-                dst[(size_t)grow * ld + col] = v;
-                if (exp) pt_out[(size_t)(col - pt_col) * np + grow] = v;
-            }
+        for (int reg = 0; reg < 16; ++reg) {
+            const int grow = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+            ov[reg] = acc[reg] + cin[reg];
+            dst[(size_t)grow * ld + col] = ov[reg];
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            panel_export_store4(ex, tstride, b, np, col, row0 + wr * 32 + 8 * q + 4 * lhalf, ov[4 * q], ov[4 * q + 1],
+                                ov[4 * q + 2], ov[4 * q + 3]);
+    }
 }
 
 // ---- getInvertedMatrix counterpart: undo the column permutation ----------------
@@ -775,60 +971,74 @@ __global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *
     }
 }
 
-#ifndef MI32_STAMPS
-template <int NT, int RPT, int W>
-static void launch_panel(const BlockedPlan &p, const BlockedWs &ws, int c0, int sub, int *rowsrc, int batch,
-                         int *d_status, hipStream_t stream)
-{
-    hipLaunchKernelGGL((gj_panel_kernel<NT, RPT, W>), dim3(batch), dim3(NT), 2 * RPT * NT * sizeof(int), stream,
-                       ws.pt[sub & 1], ws.gt, p.np, p.n, ws.tstride, c0, c0, ws.submap, rowsrc, ws.orig, sub == 0,
-                       ws.prn, d_status);
-}
 
-// The panel kernel handles the np - c0 rows at or below the block: the smallest thread geometry that holds
-// them (fewer waves and fewer rows per lane both shorten a pivot step).
-static bool dispatch_panel(const BlockedPlan &p, const BlockedWs &ws, int w, int c0, int sub, int *rowsrc, int batch,
-                           int *d_status, hipStream_t stream)
+template <int NT, int RPT, int W, bool FUSED>
+static hipError_t launch_subpanel(const SubpanelArgs &A, int nwgs, hipStream_t stream)
 {
-    int nt, rpt;
-    panel_geometry(p, p.np - c0, nt, rpt);
-#define MI32_PANEL_CASE(T, R, WW)                                                  \
-    if (nt == T && rpt == R && w == WW) {                                          \
-        launch_panel<T, R, WW>(p, ws, c0, sub, rowsrc, batch, d_status, stream);   \
-        return true;                                                               \
+    constexpr size_t lds = subpanel_lds_bytes<NT, RPT, W, FUSED>();
+    if (lds > 48 * 1024) {  // more dynamic LDS than the default limit: raise it once per device
+        static bool attr_set_dev[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!attr_set_dev[dev & 63]) {
+            hipError_t e = hipFuncSetAttribute((const void *)gj_subpanel_kernel<NT, RPT, W, FUSED>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set_dev[dev & 63] = true;
+        }
     }
-    MI32_PANEL_CASE(256, 1, 32) MI32_PANEL_CASE(256, 1, 16) MI32_PANEL_CASE(256, 1, 8) MI32_PANEL_CASE(256, 1, 4)
-    MI32_PANEL_CASE(512, 1, 32) MI32_PANEL_CASE(512, 2, 32) MI32_PANEL_CASE(512, 4, 32) MI32_PANEL_CASE(1024, 1, 32)
-    MI32_PANEL_CASE(1024, 2, 32)
-    MI32_PANEL_CASE(512, 1, 16) MI32_PANEL_CASE(512, 2, 16) MI32_PANEL_CASE(512, 4, 16) MI32_PANEL_CASE(512, 8, 16)
-    MI32_PANEL_CASE(512, 1, 8) MI32_PANEL_CASE(512, 2, 8) MI32_PANEL_CASE(512, 4, 8) MI32_PANEL_CASE(512, 8, 8)
-    MI32_PANEL_CASE(512, 1, 4) MI32_PANEL_CASE(512, 2, 4) MI32_PANEL_CASE(512, 4, 4) MI32_PANEL_CASE(512, 8, 4)
-    MI32_PANEL_CASE(1024, 1, 16) MI32_PANEL_CASE(1024, 2, 16) MI32_PANEL_CASE(1024, 4, 16)
-    MI32_PANEL_CASE(1024, 1, 8) MI32_PANEL_CASE(1024, 2, 8) MI32_PANEL_CASE(1024, 4, 8) MI32_PANEL_CASE(1024, 8, 8)
-    MI32_PANEL_CASE(1024, 1, 4) MI32_PANEL_CASE(1024, 2, 4) MI32_PANEL_CASE(1024, 4, 4) MI32_PANEL_CASE(1024, 8, 4)
-    MI32_PANEL_CASE(1024, 16, 4)
-#undef MI32_PANEL_CASE
-    return false;
+    hipLaunchKernelGGL((gj_subpanel_kernel<NT, RPT, W, FUSED>), dim3(nwgs), dim3(NT), lds, stream, A);
+    return hipSuccess;
 }
 
-// in-block update: columns [C0, C0+kb) of the block, K = w, G_s from the compact panel; exports the
-// next sub-panel's columns (if it lies in this block) into pt
-static void launch_inner_update(const BlockedPlan &p, const BlockedWs &ws, int w, const float *x, float *y, int c0,
-                                int C0, int kb, int sub, int batch, hipStream_t stream)
+// One launch of the sub-panel pipeline:
+//  * panel(s) and update(s-1) together (fused blocks): the workgroup size is the panel's, the update tiles are
+//    packed NT / 256 to a workgroup;
+//  * panel(s) alone: the smallest thread geometry that holds its rows (fewer waves and fewer rows per lane both
+//    shorten a pivot step);
+//  * update(t) alone: 256-thread workgroups, one tile each.
+static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelArgs &A, hipStream_t stream)
 {
-    const dim3 grid(kb / 64, p.np / 64, batch);
-    const int next = c0 + w;
-    const int pt_col = (next < C0 + kb) ? next : -(1 << 30);
-    // reads sub-panel `sub`'s input panel (rows above the block) and writes the next one's: two buffers
-#define MI32_INNER(BKV)                                                                                             \
-    hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, BKV, true>), grid, dim3(256), 0, stream, x, y, ws.gt,          \
-                       ws.tstride, p.np, p.ld, ws.mstride, c0, BKV, C0, ws.submap, 0, ws.pt[(sub + 1) & 1], ws.tstride, \
-                       pt_col, w, 0, 0, ws.pt[sub & 1], ws.prn, c0)
-    if (w == 32) MI32_INNER(32);
-    else if (w == 16) MI32_INNER(16);
-    else if (w == 8) MI32_INNER(8);
-    else MI32_INNER(4);
-#undef MI32_INNER
+    const int tiles = A.upd_on ? (A.kb / 64) * (p.np / 64) : 0;
+    if (!A.panel_on) {
+        const dim3 grid(A.batch * tiles);
+        if (w == 32) hipLaunchKernelGGL((gj_inblock_update_kernel<32>), grid, dim3(256), 0, stream, A);
+        else if (w == 16) hipLaunchKernelGGL((gj_inblock_update_kernel<16>), grid, dim3(256), 0, stream, A);
+        else if (w == 8) hipLaunchKernelGGL((gj_inblock_update_kernel<8>), grid, dim3(256), 0, stream, A);
+        else hipLaunchKernelGGL((gj_inblock_update_kernel<4>), grid, dim3(256), 0, stream, A);
+        return hipSuccess;
+    }
+    int nt, rpt;
+    panel_geometry(p, p.np - A.row_lo, nt, rpt);
+    const bool fused = A.upd_on != 0;
+    const int nwgs = A.batch + A.batch * (tiles / (nt / 256));
+#define MI32_SUBPANEL_CASE(T, R, WW)                                                                   \
+    if (nt == T && rpt == R && w == WW && !fused) return launch_subpanel<T, R, WW, false>(A, nwgs, stream);
+#define MI32_SUBPANEL_FUSED(T, R, WW)                                                                  \
+    if (nt == T && rpt == R && w == WW && fused) return launch_subpanel<T, R, WW, true>(A, nwgs, stream);
+    MI32_SUBPANEL_CASE(256, 1, 32) MI32_SUBPANEL_CASE(256, 1, 16) MI32_SUBPANEL_CASE(256, 1, 8) MI32_SUBPANEL_CASE(256, 1, 4)
+    MI32_SUBPANEL_CASE(512, 1, 32) MI32_SUBPANEL_CASE(512, 2, 32) MI32_SUBPANEL_CASE(512, 4, 32)
+    MI32_SUBPANEL_CASE(1024, 1, 32) MI32_SUBPANEL_CASE(1024, 2, 32)
+    MI32_SUBPANEL_CASE(512, 1, 16) MI32_SUBPANEL_CASE(512, 2, 16) MI32_SUBPANEL_CASE(512, 4, 16) MI32_SUBPANEL_CASE(512, 8, 16)
+    MI32_SUBPANEL_CASE(512, 1, 8) MI32_SUBPANEL_CASE(512, 2, 8) MI32_SUBPANEL_CASE(512, 4, 8) MI32_SUBPANEL_CASE(512, 8, 8)
+    MI32_SUBPANEL_CASE(512, 1, 4) MI32_SUBPANEL_CASE(512, 2, 4) MI32_SUBPANEL_CASE(512, 4, 4) MI32_SUBPANEL_CASE(512, 8, 4)
+    MI32_SUBPANEL_CASE(1024, 1, 16) MI32_SUBPANEL_CASE(1024, 2, 16) MI32_SUBPANEL_CASE(1024, 4, 16)
+    MI32_SUBPANEL_CASE(1024, 1, 8) MI32_SUBPANEL_CASE(1024, 2, 8) MI32_SUBPANEL_CASE(1024, 4, 8) MI32_SUBPANEL_CASE(1024, 8, 8)
+    MI32_SUBPANEL_CASE(1024, 1, 4) MI32_SUBPANEL_CASE(1024, 2, 4) MI32_SUBPANEL_CASE(1024, 4, 4) MI32_SUBPANEL_CASE(1024, 8, 4)
+    MI32_SUBPANEL_CASE(1024, 16, 4)
+    // fused launches exist for the geometries of at most kFusedRows rows (blocked_invert)
+    MI32_SUBPANEL_FUSED(256, 1, 32) MI32_SUBPANEL_FUSED(256, 1, 16) MI32_SUBPANEL_FUSED(256, 1, 8) MI32_SUBPANEL_FUSED(256, 1, 4)
+    MI32_SUBPANEL_FUSED(512, 1, 32) MI32_SUBPANEL_FUSED(512, 2, 32) MI32_SUBPANEL_FUSED(512, 4, 32)
+    MI32_SUBPANEL_FUSED(1024, 1, 32) MI32_SUBPANEL_FUSED(1024, 2, 32)
+    MI32_SUBPANEL_FUSED(512, 1, 16) MI32_SUBPANEL_FUSED(512, 2, 16) MI32_SUBPANEL_FUSED(512, 4, 16)
+    MI32_SUBPANEL_FUSED(1024, 1, 16) MI32_SUBPANEL_FUSED(1024, 2, 16)
+    MI32_SUBPANEL_FUSED(512, 1, 8) MI32_SUBPANEL_FUSED(512, 2, 8) MI32_SUBPANEL_FUSED(512, 4, 8)
+    MI32_SUBPANEL_FUSED(1024, 1, 8) MI32_SUBPANEL_FUSED(1024, 2, 8)
+    MI32_SUBPANEL_FUSED(512, 1, 4) MI32_SUBPANEL_FUSED(512, 2, 4) MI32_SUBPANEL_FUSED(512, 4, 4)
+    MI32_SUBPANEL_FUSED(1024, 1, 4) MI32_SUBPANEL_FUSED(1024, 2, 4)
+#undef MI32_SUBPANEL_CASE
+#undef MI32_SUBPANEL_FUSED
+    return hipErrorInvalidValue;
 }
 
 // Look-ahead: the rank-bw update of block b is split into (A) the columns of block b+1, which the next
@@ -847,10 +1057,16 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     // (measured: 8192^2 51 -> 45 ms, 16384^2 399 -> 330 ms, 4096^2 11.2 -> 11.0 ms, 2048^2 4.2 -> 4.4 ms)
     const bool lookahead = ex.aux != nullptr && ex.n_events >= 4 && ex.aux_workgroups > 0 && batch == 1 && np >= 4096;
     hipError_t e;
+    int fused_rows = 2048;  // see "Fused mode" below; fused instances exist for at most 2048 rows
+    if (const char *ev = std::getenv("MI32_FUSED_ROWS")) fused_rows = std::atoi(ev) < 2048 ? std::atoi(ev) : 2048;
+    const PanelExport no_export = {ws.pt[0], ws.pt_bstride, -(1 << 30), 1, 0};
     {
+        // the first two sub-panels of the first block are exported as they are: the first has no pending
+        // update at all, the second gets the first one's update in its panel's prologue
         ProfScope ps(prof, KC_INIT, stream);
+        const PanelExport ex0 = {ws.pt[0], ws.pt_bstride, 0, p.wblk[0], np <= fused_rows ? 2 : 1};
         hipLaunchKernelGGL(blocked_init_kernel, dim3((np + 255) / 256, (np + 15) / 16, batch), dim3(256), 0, stream,
-                           d_a, p.n, np, p.ld, ws.mstride, ws.m0, ws.pt[0], ws.tstride, p.wblk[0], ws.orig, ws.submap, d_status);
+                           d_a, p.n, np, p.ld, ws.mstride, ws.m0, ex0, ws.tstride, ws.orig, d_status);
     }
     if (lookahead) {  // whatever still runs on the second stream from an earlier call shares this workspace
         if ((e = hipEventRecord(ex.events[0], ex.aux)) != hipSuccess) return e;
@@ -881,25 +1097,82 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
         int *rowsrc = ws.rowsrc[blk & 1];
         const int w = p.wblk[blk];                                       // sub-panel width of this block
         const int w_next = (blk + 1 < p.nblk) ? p.wblk[blk + 1] : w;     // ... and of the next one
+        const int S = kb / w;                                            // sub-panels of this block (even)
+        // Fused mode: launch s = panel(s) || update(s-1), the panel applies update(s-1) to its own columns in a
+        // prologue.  It pays while the panel workgroup holds at most 2 rows per lane (measured: 2048^2 3.23 ->
+        // 3.06 ms, 1024^2 1.40 -> 1.27 ms); with more rows the prologue (rows x W x W fmaf on ONE CU) costs what
+        // the update launch did (4096^2: 8.9 -> 9.5 ms), so those blocks keep panel(s) and update(s) apart.
+        const bool fused = (np - C0) <= fused_rows;
         float *x = cur, *y = oth;  // the block's panel columns alternate between the two copies
-        for (int s = 0; s * w < kb; ++s) {
-            const int c0 = C0 + s * w;
-            {
-                ProfScope ps(prof, KC_PANEL, stream);
-                if (!dispatch_panel(p, ws, w, c0, s, rowsrc, batch, d_status, stream)) return hipErrorInvalidValue;
+        for (int s = 0; s <= S; ++s) {
+            SubpanelArgs P = {};   // the panel half
+            P.np = np; P.n = p.n; P.ld = p.ld; P.batch = batch;
+            P.mstride = ws.mstride; P.tstride = ws.tstride;
+            P.u_exp = no_export;
+            SubpanelArgs U = P;    // the update half
+            if (s < S) {
+                P.panel_on = 1;
+                P.c0 = C0 + s * w;
+                P.has_prev = fused && (s > 0);
+                P.c0_prev = P.c0 - w;
+                P.row_lo = P.has_prev ? P.c0_prev : P.c0;  // fused: the W pivot rows of s-1 are needed once more
+                P.first_in_block = (s == 0);
+                P.pt_in = ws.pt[s % 3];
+                P.gt_prev = ws.gt[(s + 1) & 1];
+                P.gt_out = ws.gt[s & 1];
+                P.invsub_prev = ws.invsub[(s + 1) & 1];
+                P.submap_out = ws.submap[s & 1];
+                P.invsub_out = ws.invsub[s & 1];
+                P.rowsrc = rowsrc;
+                P.orig = ws.orig;
+                P.aux_out = ws.aux[s & 1];
+                P.status = d_status;
             }
-            {
-                ProfScope ps(prof, KC_UPDATE_IN, stream);
-                launch_inner_update(p, ws, w, x, y, c0, C0, kb, s, batch, stream);
+            if (s > 0) {
+                const int t = s - 1;
+                U.upd_on = 1;
+                U.u_c0 = C0 + t * w;
+                U.u_has_prev = fused && (t > 0);
+                U.u_above_hi = U.u_has_prev ? U.u_c0 - w : U.u_c0;  // = the first row panel(t) held
+                U.C0 = C0; U.kb = kb;
+                U.x = x; U.y = y;
+                U.u_gt = ws.gt[t & 1];
+                U.u_submap = ws.submap[t & 1];
+                U.u_pt_in = ws.pt[t % 3];
+                U.u_aux = ws.aux[t & 1];
+                // fused: sub-panel t+2's columns (t+1's are brought up to date by its own panel);
+                // otherwise sub-panel t+1's, fully up to date
+                const int tx = fused ? t + 2 : t + 1;
+                if (tx < S) U.u_exp = PanelExport{ws.pt[tx % 3], ws.pt_bstride, C0 + tx * w, w, 1};
             }
-            float *t = x; x = y; y = t;
+            if (fused) {
+                SubpanelArgs A = P;  // one launch: panel(s) || update(s-1)
+                A.upd_on = U.upd_on; A.u_c0 = U.u_c0; A.u_has_prev = U.u_has_prev; A.u_above_hi = U.u_above_hi;
+                A.C0 = U.C0; A.kb = U.kb; A.x = U.x; A.y = U.y; A.u_gt = U.u_gt; A.u_submap = U.u_submap;
+                A.u_pt_in = U.u_pt_in; A.u_aux = U.u_aux; A.u_exp = U.u_exp;
+                // a fused launch is accounted to the panel while there is one (it is the critical path)
+                ProfScope ps(prof, A.panel_on ? KC_PANEL : KC_UPDATE_IN, stream);
+                if ((e = dispatch_subpanel(p, w, A, stream)) != hipSuccess) return e;
+            } else {
+                if (U.upd_on) {  // update(s-1) first: panel(s) reads the columns it exports
+                    ProfScope ps(prof, KC_UPDATE_IN, stream);
+                    if ((e = dispatch_subpanel(p, w, U, stream)) != hipSuccess) return e;
+                }
+                if (P.panel_on) {
+                    ProfScope ps(prof, KC_PANEL, stream);
+                    if ((e = dispatch_subpanel(p, w, P, stream)) != hipSuccess) return e;
+                }
+            }
+            if (s > 0) { float *t2 = x; x = y; y = t2; }
         }
         // x now holds the block's G; every other column is still valid in `cur` only
         if (kb < np) {
             const int next = C0 + kb;  // first column of the next block
             const bool has_next = next < np;
             const int kb_next = has_next ? ((next + p.bw <= np) ? p.bw : np - next) : 0;
-            const int pt_col = has_next ? next : -(1 << 30);
+            // the next block's first two sub-panels, fully updated, for its first two panels
+            const PanelExport exn =
+                has_next ? PanelExport{ws.pt[0], ws.pt_bstride, next, w_next, (np - next) <= fused_rows ? 2 : 1} : no_export;
             const int copy = (x != oth) ? 1 : 0;
             if (pending_b) {  // this update reads all of `cur` and overwrites `oth`: the previous (B) must be done
                 if ((e = hipStreamWaitEvent(stream, ex.events[ev], 0)) != hipSuccess) return e;
@@ -911,12 +1184,12 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                                    ws.mstride, np, p.ld, C0, ws.gk, ws.gkstride);
             }
             if (lookahead && has_next) {
-                {   // (A): the next block's columns, on the main stream; exports the next sub-panel
+                {   // (A): the next block's columns, on the main stream; exports the next sub-panels
                     ProfScope ps(prof, KC_UPDATE_OUT, stream);
                     // small tiles: only kb_next columns, so 64x64 gives 4x the workgroups of 128x128
-                    hipLaunchKernelGGL((gj_rank_update_kernel<64, 64, 32, false>), dim3(kb_next / 64, np / 64, batch),
-                                       dim3(256), 0, stream, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, next,
-                                       rowsrc, copy, ws.pt[0], ws.tstride, pt_col, w_next, 0, 0, nullptr, nullptr, 0);
+                    hipLaunchKernelGGL((gj_rank_update_kernel<32>), dim3(kb_next / 64, np / 64, batch), dim3(256), 0,
+                                       stream, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, next, rowsrc, exn,
+                                       ws.tstride);
                 }
                 // (B): everything else, on the second stream, after this block's panel phase
                 ev = (ev + 1) % (ex.n_events / 2);
@@ -929,7 +1202,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                     // that one CU holds at most one of them -> the remaining CUs stay free for the main stream
                     hipLaunchKernelGGL((gj_rank_bw2_persistent_kernel<MI32_BW_BK>), dim3(ex.aux_workgroups, batch),
                                        dim3(256), lds_persistent, ex.aux, cur, oth, x, ws.mstride, ws.gk, ws.gkstride, np,
-                                       p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt[0], ws.tstride, -(1 << 30), w_next, next,
+                                       p.ld, ws.mstride, C0, kb, rowsrc, copy, no_export, ws.tstride, next,
                                        next + kb_next);
                 }
                 if ((e = hipEventRecord(ex.events[ev], ex.aux)) != hipSuccess) return e;
@@ -938,8 +1211,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 ProfScope ps(prof, KC_UPDATE_OUT, stream);
                 hipLaunchKernelGGL((gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS>), dim3((np / 128) * (np / 128), batch),
                                    dim3(256), rank_bw2_lds_bytes<MI32_BW_BK>(kb), stream, cur, oth, x, ws.mstride, ws.gk,
-                                   ws.gkstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, ws.pt[0], ws.tstride, pt_col,
-                                   w_next, 0, 0);
+                                   ws.gkstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, exn, ws.tstride, 0, 0);
             }
             float *t = cur; cur = oth; oth = t;
         } else {
@@ -963,6 +1235,5 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     }
     return hipGetLastError();
 }
-#endif  // !MI32_STAMPS
 
 }  // namespace mi32

@@ -22,6 +22,35 @@
 
 namespace mi32 {
 
+// Where a wide kernel exports freshly computed columns for the panel workgroup: columns
+// [col, col + w * count) go to `count` consecutive compact panels (w columns each) starting at `base`.
+struct PanelExport {
+    float *base;     // first compact panel, matrix 0
+    size_t bstride;  // floats between consecutive compact panels
+    int col, w, count;
+};
+__device__ __forceinline__ void panel_export_store(const PanelExport &e, size_t tstride, int b, int np, int col, int grow,
+                                                   float v)
+{
+    const int idx = col - e.col;
+    if ((unsigned)idx < (unsigned)(e.w * e.count))
+        e.base[(size_t)(idx / e.w) * e.bstride + (size_t)b * tstride + (size_t)(idx % e.w) * np + grow] = v;
+}
+
+// four consecutive rows (grow4 a multiple of 4) of one exported column: one 16-byte store
+__device__ __forceinline__ void panel_export_store4(const PanelExport &e, size_t tstride, int b, int np, int col,
+                                                    int grow4, float v0, float v1, float v2, float v3)
+{
+    const int idx = col - e.col;
+    if ((unsigned)idx < (unsigned)(e.w * e.count)) {
+        typedef float pe_f4v __attribute__((ext_vector_type(4)));
+        pe_f4v v;
+        v[0] = v0; v[1] = v1; v[2] = v2; v[3] = v3;
+        *reinterpret_cast<pe_f4v *>(e.base + (size_t)(idx / e.w) * e.bstride + (size_t)b * tstride +
+                                    (size_t)(idx % e.w) * np + grow4) = v;
+    }
+}
+
 typedef float rb_float16v __attribute__((ext_vector_type(16)));
 typedef float rb_f4v __attribute__((ext_vector_type(4)));
 
@@ -86,8 +115,8 @@ template <int BK>
 __device__ __forceinline__ void rank_bw2_tile(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
     const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
-    const int *__restrict__ map_all, int copy_panel, float *__restrict__ pt_out_all, size_t tstride, int pt_col,
-    int pt_w, int skip_lo, int skip_hi, int b, int rt, int ct, float *rb_smem)
+    const int *__restrict__ map_all, int copy_panel, const PanelExport &ex, size_t tstride, int skip_lo, int skip_hi,
+    int b, int rt, int ct, float *rb_smem)
 {
     constexpr int BM = 128, BN = 128;
     constexpr int ND = BK / 8;  // LDS-DMA instructions per wave per operand per stage (each moves 2 k-rows)
@@ -105,7 +134,6 @@ __device__ __forceinline__ void rank_bw2_tile(
     float *dst = dst_all + (size_t)b * mstride;
     const float *gk = gk_all + (size_t)b * gkstride;
     const int *map = map_all + (size_t)b * np;
-    float *pt_out = pt_out_all + (size_t)b * tstride;
 
     if (col0 >= skip_lo && col0 < skip_hi) return;
     if (col0 >= c0 && col0 + BN <= c0 + kdim) {  // tile inside the panel: those columns are G itself
@@ -185,7 +213,6 @@ __device__ __forceinline__ void rank_bw2_tile(
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
             const int col = col0 + wc * 64 + tn * 32 + lcol;
-            const bool exp = (col >= pt_col && col < pt_col + pt_w);  // next sub-panel's column
             // the old values C (row-mapped); the rows of the block itself start from 0.  Block bounds are
             // multiples of 128, so a whole tile is either inside the block or outside it.
             float cv[16];
@@ -201,10 +228,14 @@ __device__ __forceinline__ void rank_bw2_tile(
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int grow = row0 + wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                const float v = acc[tm][tn][reg] + cv[reg];
-                dst[(size_t)grow * ld + col] = v;
-                if (exp) pt_out[(size_t)(col - pt_col) * np + grow] = v;
+                cv[reg] += acc[tm][tn][reg];
+                dst[(size_t)grow * ld + col] = cv[reg];
             }
+            // the next block's first sub-panels, compact and transposed: registers 4q .. 4q+3 are 4 consecutive rows
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                panel_export_store4(ex, tstride, b, np, col, row0 + wr * 64 + tm * 32 + 8 * q + 4 * lhalf, cv[4 * q],
+                                    cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
         }
 }
 
@@ -213,14 +244,13 @@ template <int BK, int WPS>
 __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
     const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
-    const int *__restrict__ map_all, int copy_panel, float *__restrict__ pt_out_all, size_t tstride, int pt_col,
-    int pt_w, int skip_lo, int skip_hi)
+    const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo, int skip_hi)
 {
     extern __shared__ __attribute__((aligned(16))) float rb_smem[];
     int rt, ct;
     rb_tile_of(blockIdx.x, np / 128, rt, ct);
     rank_bw2_tile<BK>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all, copy_panel,
-                      pt_out_all, tstride, pt_col, pt_w, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
+                      ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
 }
 
 // Persistent, residency-limited flavour for the look-ahead half (see blocked_invert): gridDim.x workgroups
@@ -232,8 +262,7 @@ template <int BK>
 __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
     const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
-    const int *__restrict__ map_all, int copy_panel, float *__restrict__ pt_out_all, size_t tstride, int pt_col,
-    int pt_w, int skip_lo, int skip_hi)
+    const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo, int skip_hi)
 {
     extern __shared__ __attribute__((aligned(16))) float rb_smem[];
     const int T = np / 128;
@@ -241,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
         int rt, ct;
         rb_tile_of(id, T, rt, ct);
         rank_bw2_tile<BK>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
-                          copy_panel, pt_out_all, tstride, pt_col, pt_w, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
+                          copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
         __syncthreads();  // the next tile re-uses the LDS buffers and maps
     }
 }

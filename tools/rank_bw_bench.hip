@@ -72,7 +72,7 @@ int main(int argc, char **argv)
     };
     auto run2 = [&]() {
         hipLaunchKernelGGL((gj_rank_bw2_kernel<RB_BK, RB_WPS>), dim3(T * T, batch), dim3(256), lds2, 0, src, d2, g, mstride, gk,
-                           gkstride, np, ld, mstride, c0, kdim, map, 1, pt2, tstride, pt_col, pt_w, 0, 0);
+                           gkstride, np, ld, mstride, c0, kdim, map, 1, PanelExport{pt2, 0, pt_col, pt_w, 1}, tstride, 0, 0);
     };
     run1(); runT(); run2();
     CK(hipDeviceSynchronize());
