@@ -70,6 +70,11 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 static constexpr int kMaxBW = 512;  // widest outer block (rows of the transposed panel Gk)
 
 static constexpr int kMaxW = 32;  // widest sub-panel (columns kept in registers)
+// A panel of more than kPanelGroupRows candidate rows is shared by up to kMaxPanelGroups workgroups (one CU
+// each, <= 4 rows per lane at 1024 threads) that exchange every step's local winner through global memory.
+static constexpr int kMaxPanelGroups = 4;
+static constexpr int kPanelGroupRows = 4096;
+static constexpr int kXchGranules = 2 * kMaxPanelGroups * 32;  // 8-byte granules per matrix: [parity][group][32]
 
 // Panel-kernel geometry: NT threads hold the rows at or below the block x w columns in registers, rpt rows
 // each (1024 threads leave <= 128 VGPRs per lane, i.e. rpt * w <= 64 floats of slab).
@@ -78,6 +83,11 @@ static constexpr int kMaxW = 32;  // widest sub-panel (columns kept in registers
 static void panel_geometry(const BlockedPlan &p, int nrows, int &nt, int &rpt)
 {
     rpt = 1;
+    if (p.multi_panel && nrows > kPanelGroupRows) {  // shared by ceil(nrows / 4096) workgroups of 1024 x 4 rows
+        nt = 1024;
+        rpt = 4;
+        return;
+    }
     if (nrows <= 256) nt = 256;
     else if (nrows <= 512) nt = 512;
     else {
@@ -86,7 +96,7 @@ static void panel_geometry(const BlockedPlan &p, int nrows, int &nt, int &rpt)
     }
 }
 
-BlockedPlan make_blocked_plan(int n, int w, int bw)
+BlockedPlan make_blocked_plan(int n, int w, int bw, int batch)
 {
     BlockedPlan p;
     p.n = n;
@@ -107,6 +117,10 @@ BlockedPlan make_blocked_plan(int n, int w, int bw)
     }
     p.nthreads_panel = nt;
     p.rpt = rpt;
+    // Multi-workgroup panels need every workgroup of a panel resident at once and a whole CU each; with the
+    // look-ahead kernel holding all but 32 CUs that is safe for a few matrices (MI32_MULTI_PANEL=0 turns it off).
+    p.multi_panel = (nt == 1024 && p.np > kPanelGroupRows && batch * kMaxPanelGroups <= 16) ? 1 : 0;
+    if (const char *e = std::getenv("MI32_MULTI_PANEL")) p.multi_panel = p.multi_panel && std::atoi(e) != 0;
     if (w <= 0) w = 16;  // 32 is selectable where it fits, but measured slower (4.6 vs 4.2 ms at 2048^2)
     w = (w >= 32) ? 32 : (w >= 16) ? 16 : (w >= 8 ? 8 : 4);
     p.w = w;
@@ -136,6 +150,7 @@ struct BlockedWs {
     float *gt[2];       // compact transposed panel outputs G_s: gt[s & 1]
     float *aux[2];      // per sub-panel: the W normalised pivot rows, and the previous sub-panel's pivot rows
                         // restricted to this sub-panel's columns (2 x kMaxW x kMaxW floats per matrix)
+    unsigned long long *xch;  // exchange granules of the multi-workgroup panels, kXchGranules per matrix
     float *gk;          // the block's panel G transposed, bw x np: A operand of the rank-bw update
     size_t gkstride;    // floats per matrix in gk
     int *submap[2], *invsub[2];  // per sub-panel: position after s -> index in order after s-1, and its inverse
@@ -173,6 +188,8 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
         if (o) o->aux[i] = (float *)(c + off);
         off += abytes;
     }
+    if (o) o->xch = (unsigned long long *)(c + off);
+    off += align256((size_t)kXchGranules * sizeof(unsigned long long) * batch);
     const size_t gkbytes = align256((size_t)(p.bw < kMaxBW ? p.bw : kMaxBW) * p.np * sizeof(float));
     if (o) { o->gk = (float *)(c + off); o->gkstride = gkbytes / sizeof(float); }
     off += gkbytes * batch;
@@ -262,6 +279,7 @@ struct __attribute__((aligned(16))) PanelShared {
     unsigned long long key[W];  // one cross-wave arg-max word per step, zeroed at kernel start
     float prn_all[W][W];        // the normalised pivot row of every step, exported for the rows above the block
     float bprev[W][W];          // the previous sub-panel's W pivot rows, restricted to this sub-panel's columns
+    unsigned gx[2][kMaxPanelGroups][W + 2];  // multi-workgroup panels: every workgroup's winner of this step
 };
 
 // which matrix row register row k of thread tid holds: V consecutive rows per thread so that the
@@ -297,9 +315,17 @@ __device__ __forceinline__ int panel_row(int tid, int k)
 //    every lane (no table of who holds which position);
 //  * a NaN is never special-cased in the search: its bit pattern wins the unsigned max, the step then has
 //    a NaN pivot and the winning wave flags the matrix as singular -- the result is poisoned either way.
-template <int NT, int RPT, int W, int R>
+// What a workgroup of a multi-workgroup panel knows about the others (MULTI instances only).
+struct PanelGroup {
+    int ngroups, grp;           // workgroups sharing this panel, and which one this is
+    unsigned long long *xch;    // this matrix's exchange granules, [2][kMaxPanelGroups][32] x {payload, tag}
+    unsigned tag_base;          // unique per launch within a call (<< 8 | step + 1 = the tag of a step)
+    bool timed_out;
+};
+
+template <int NT, int RPT, int W, int R, bool MULTI>
 __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[RPT], PanelShared<NT / 64, W> &sh,
-                                           int wave_u, int c0, bool wave_active, bool &singular)
+                                           int wave_u, int c0, bool wave_active, bool &singular, PanelGroup &pg)
 {
     constexpr int par = R & 1;
     const int slot = c0 + R;
@@ -364,16 +390,69 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
         }
     }
     __syncthreads();
-    const unsigned long long key = sh.key[R];
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(key & 0xFFFFFFFFull));
-    const int p = (int)(0xFFFFFu - (lo >> 8));
-    const int wv = (int)(lo & 0xFFu);
-    if (key == 0ull) singular = true;  // cannot happen (position `slot` is always a live candidate); never trust it
+    unsigned long long key = sh.key[R];
+    unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(key & 0xFFFFFFFFull));
     float prn[W];  // prn[R] = 1/piv (the identity column's entry), prn[c] = normalised pivot row
+    bool my_group_won = true;
+    if constexpr (MULTI) {
+        // -- the workgroups of this panel exchange their local winners: W normalised entries + the 64-bit key,
+        //    as 8-byte {payload, tag} granules, each written by ONE agent-scope store and polled with agent-scope
+        //    loads (a granule is its own flag: MI355X_MICROARCH.md, handoff-1to1).  The tag is unique per step
+        //    and launch and the buffers alternate with the step parity: a workgroup can only be one step ahead.
+        //    Every spin is bounded: on a time-out the matrix is flagged and the step goes on with what it has.
+        const unsigned tag = (pg.tag_base << 8) | (unsigned)(R + 1);
+        unsigned long long *xq = pg.xch + (size_t)par * (kMaxPanelGroups * 32);
+        if (wave_u == 0 && lane < W + 2) {
+            const int lwv = (int)(lo & 0xFFu);
+            unsigned payload;
+            if (lane < W) payload = __float_as_uint(sh.prn[par][lwv][lane]);
+            else if (lane == W) payload = (lo & ~0xFFu) | ((unsigned)pg.grp << 4) | (unsigned)lwv;
+            else payload = (unsigned)(key >> 32);
+            __hip_atomic_store(&xq[pg.grp * 32 + lane], ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (wave_u < pg.ngroups) {  // wave g collects workgroup g's record (its own workgroup's too)
+            const unsigned long long *src = xq + wave_u * 32;
+            unsigned long long v = 0ull;
+            int spins = 0;
+            for (;;) {
+                if (lane < W + 2) v = __hip_atomic_load(&src[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (lane >= W + 2) || ((unsigned)(v >> 32) == tag);
+                if (__all(ok)) break;
+                if (++spins > (1 << 22)) { pg.timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane < W + 2) sh.gx[par][wave_u][lane] = (unsigned)v;
+        }
+        __syncthreads();
+        int gw = 0;
+        key = ((unsigned long long)sh.gx[par][0][W + 1] << 32) | sh.gx[par][0][W];
 #pragma unroll
-    for (int c = 0; c < W; c += 4) {
-        const float4 t = *reinterpret_cast<const float4 *>(&sh.prn[par][wv][c]);
-        prn[c] = t.x; prn[c + 1] = t.y; prn[c + 2] = t.z; prn[c + 3] = t.w;
+        for (int g = 1; g < kMaxPanelGroups; ++g)
+            if (g < pg.ngroups) {
+                const unsigned long long kg = ((unsigned long long)sh.gx[par][g][W + 1] << 32) | sh.gx[par][g][W];
+                if (kg > key) { key = kg; gw = g; }
+            }
+        gw = __builtin_amdgcn_readfirstlane(gw);
+        lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(key & 0xFFFFFFFFull));
+        my_group_won = (gw == pg.grp);
+#pragma unroll
+        for (int c = 0; c < W; c += 4) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(&sh.gx[par][gw][c]);
+            prn[c] = __uint_as_float(t.x); prn[c + 1] = __uint_as_float(t.y);
+            prn[c + 2] = __uint_as_float(t.z); prn[c + 3] = __uint_as_float(t.w);
+        }
+        if (wave_u == 0 && lane < W) sh.prn_all[R][lane] = __uint_as_float(sh.gx[par][gw][lane]);
+    }
+    const int p = (int)(0xFFFFFu - (lo >> 8));
+    const int wv = MULTI ? (int)(lo & 0xFu) : (int)(lo & 0xFFu);
+    if (key == 0ull) singular = true;  // cannot happen (position `slot` is always a live candidate); never trust it
+    if constexpr (!MULTI) {
+#pragma unroll
+        for (int c = 0; c < W; c += 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(&sh.prn[par][wv][c]);
+            prn[c] = t.x; prn[c + 1] = t.y; prn[c + 2] = t.z; prn[c + 3] = t.w;
+        }
     }
     // -- fixColumn on the slab, branch-free; the pivot column holds the implicit identity column, whose
     //    entry is 0 in every row but the pivot row.  The pivot row itself is overwritten right after.
@@ -391,11 +470,11 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
     }
     // ... and the winner's candidate row (its wave knows lane and row) becomes the pivot row: normalised
     // values, label `slot`, no longer a candidate
-    if (wave_u == wv) {
+    if (my_group_won && wave_u == wv) {
         // this wave's scratch slot still holds the winning row as found: its pivot entry decides "singular"
         const float cpiv = sh.cand[wave_u][R];
         if (cpiv == 0.0f || cpiv != cpiv) singular = true;
-        if (lane < W) sh.prn_all[R][lane] = sh.prn[par][wv][lane];
+        if (!MULTI && lane < W) sh.prn_all[R][lane] = sh.prn[par][wv][lane];
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (own_k == k) {
@@ -408,12 +487,12 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
     }
 }
 
-template <int NT, int RPT, int W, int... Rs>
+template <int NT, int RPT, int W, bool MULTI, int... Rs>
 __device__ __forceinline__ void panel_steps(float (&a)[RPT][W], unsigned (&npl)[RPT], PanelShared<NT / 64, W> &sh,
-                                            int wave_u, int c0, bool wave_active, bool &singular,
+                                            int wave_u, int c0, bool wave_active, bool &singular, PanelGroup &pg,
                                             std::integer_sequence<int, Rs...>)
 {
-    (panel_step<NT, RPT, W, Rs>(a, npl, sh, wave_u, c0, wave_active, singular), ...);
+    (panel_step<NT, RPT, W, Rs, MULTI>(a, npl, sh, wave_u, c0, wave_active, singular, pg), ...);
 }
 
 // Everything one fused sub-panel launch needs (passed by value).
@@ -436,6 +515,9 @@ struct SubpanelArgs {
     int *rowsrc, *orig;
     float *aux_out;          // [2][kMaxW*kMaxW] per matrix: normalised pivot rows of s; pivot rows of s-1 x columns of s
     int *status;
+    int ngroups;             // workgroups per panel (> 1: MULTI instances, kPanelGroupRows rows each)
+    unsigned long long *xch; // [batch][kXchGranules] exchange granules of the multi-workgroup panels
+    unsigned tag_base;       // unique per panel launch within a call
     // ---- update(t), t = s-1: the other workgroups (absent when upd_on == 0)
     int upd_on;
     int u_c0;        // first column of sub-panel t
@@ -460,9 +542,12 @@ constexpr size_t panel_shared_bytes()
 // panel(s) of one matrix: the whole workgroup.  smem: panel_shared_bytes + 2 * RPT * NT ints.
 // FUSED = false compiles the pending-update prologue (and the labels-at-entry indirection) out: the instances
 // with 4 and more rows per lane have no registers to spare for code they never run.
-template <int NT, int RPT, int W, bool FUSED>
-__device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, unsigned char *smem)
+// MULTI: the panel is shared by A.ngroups workgroups; this one (grp) holds the rows
+// [row_lo + grp * NT * RPT, row_lo + (grp + 1) * NT * RPT) and takes part in the per-step exchange (panel_step).
+template <int NT, int RPT, int W, bool FUSED, bool MULTI>
+__device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp, unsigned char *smem)
 {
+    static_assert(!(FUSED && MULTI), "multi-workgroup panels are never fused");
     const bool has_prev = FUSED && A.has_prev;
     constexpr int V = RPT < 4 ? RPT : 4;
     constexpr int NW = NT / 64;
@@ -473,7 +558,8 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, unsigne
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int np = A.np, c0 = A.c0, row_lo = A.row_lo;
+    const int np = A.np, c0 = A.c0;
+    const int row_lo = A.row_lo + (MULTI ? grp * (NT * RPT) : 0);  // first row THIS workgroup holds
     const float *pt = A.pt_in + (size_t)b * A.tstride;
     const int *invsub_prev = A.invsub_prev + (size_t)b * np;
     if (tid < W) sh.key[tid] = 0ull;
@@ -518,7 +604,7 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, unsigne
         s_park[(RPT + k) * NT + tid] = row < np ? orig[p0] : 0;
     }
     // rows above the block keep their place: identity entries in the maps the update kernels read
-    if (A.first_in_block)
+    if (A.first_in_block && grp == 0)
         for (int i = tid; i < row_lo; i += NT) rowsrc[i] = i;
 
     if (has_prev) {
@@ -577,7 +663,8 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, unsigne
     }
     bool singular = false;
     __syncthreads();  // sh.key[] zeroed before any wave's first atomicMax; all map reads issued
-    panel_steps<NT, RPT, W>(a, npl, sh, wave_u, c0, true, singular, std::make_integer_sequence<int, W>{});
+    PanelGroup pg = {A.ngroups, grp, A.xch + (size_t)b * kXchGranules, A.tag_base, false};
+    panel_steps<NT, RPT, W, MULTI>(a, npl, sh, wave_u, c0, true, singular, pg, std::make_integer_sequence<int, W>{});
     int pos[RPT];  // final position of every register row
 #pragma unroll
     for (int k = 0; k < RPT; ++k) pos[k] = (int)(npl[k] ^ (unsigned)((int)npl[k] >> 31));
@@ -586,16 +673,18 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, unsigne
     //    pivot rows of s-1 restricted to this sub-panel's columns
     __syncthreads();
     float *aux = A.aux_out + (size_t)b * (2 * kMaxW * kMaxW);
-    for (int i = tid; i < W * W; i += NT) {
-        aux[i] = sh.prn_all[i / W][i % W];
-        if (has_prev) aux[kMaxW * kMaxW + i] = sh.bprev[i / W][i % W];
-    }
+    if (grp == 0)
+        for (int i = tid; i < W * W; i += NT) {
+            aux[i] = sh.prn_all[i / W][i % W];
+            if (has_prev) aux[kMaxW * kMaxW + i] = sh.bprev[i / W][i % W];
+        }
     // -- G_s by label at entry (order after s-1: what update(s) reads the working copy in); the row maps
     float *gt = A.gt_out + (size_t)b * A.tstride;
     int *submap = A.submap_out + (size_t)b * np;
     int *invsub = A.invsub_out + (size_t)b * np;
     // positions retired since this map buffer was last written: identity (any earlier position already is)
-    if (tid < 4 * kMaxW && row_lo - 4 * kMaxW + tid >= 0) submap[row_lo - 4 * kMaxW + tid] = row_lo - 4 * kMaxW + tid;
+    if (grp == 0 && tid < 4 * kMaxW && row_lo - 4 * kMaxW + tid >= 0)
+        submap[row_lo - 4 * kMaxW + tid] = row_lo - 4 * kMaxW + tid;
 #pragma unroll
     for (int g = 0; g < RPT / V; ++g) {
         const int row = row_lo + panel_row<NT, RPT>(tid, g * V);
@@ -633,6 +722,7 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, unsigne
     }
     // only the wave that won a step has looked at that step's pivot: any wave may raise the flag
     if (singular && lane == 0 && A.status) A.status[b] = MI32_SINGULAR;
+    if (pg.timed_out && lane == 0 && A.status) A.status[b] = MI32_RUNTIME_ERROR;  // a partner workgroup never showed up
 }
 
 // One pivot step of a row that is not a candidate, for the in-block update tiles: the row's BK panel entries
@@ -823,11 +913,21 @@ __global__ __launch_bounds__(NT) void gj_subpanel_kernel(SubpanelArgs A)
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     if constexpr (FUSED) {
         const int npanel = A.panel_on ? A.batch : 0;
-        if ((int)blockIdx.x < npanel) panel_body<NT, RPT, W, true>(A, (int)blockIdx.x, sp_smem);
+        if ((int)blockIdx.x < npanel) panel_body<NT, RPT, W, true, false>(A, (int)blockIdx.x, 0, sp_smem);
         else inblock_update_body<W, NT / 256>(A, (int)blockIdx.x - npanel, sp_smem);
     } else {
-        panel_body<NT, RPT, W, false>(A, (int)blockIdx.x, sp_smem);
+        panel_body<NT, RPT, W, false, false>(A, (int)blockIdx.x, 0, sp_smem);
     }
+}
+
+// A panel of more than kPanelGroupRows rows: A.ngroups workgroups per matrix (all must be resident at once:
+// the host only uses this for small batches), kPanelGroupRows rows each.
+template <int W>
+__global__ __launch_bounds__(1024) void gj_panel_multi_kernel(SubpanelArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    static_assert(1024 * 4 == kPanelGroupRows, "1024 threads x 4 rows per lane");
+    panel_body<1024, 4, W, false, true>(A, (int)blockIdx.x / A.ngroups, (int)blockIdx.x % A.ngroups, sp_smem);
 }
 
 // update(t) alone: one 64 x 64 tile per 256-thread workgroup
@@ -1008,6 +1108,12 @@ static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelA
         else hipLaunchKernelGGL((gj_inblock_update_kernel<4>), grid, dim3(256), 0, stream, A);
         return hipSuccess;
     }
+    if (A.ngroups > 1) {  // multi-workgroup panel: never fused, W = 16 (what the plan gives every block then)
+        if (A.upd_on || w != 16) return hipErrorInvalidValue;
+        constexpr size_t lds = subpanel_lds_bytes<1024, 4, 16, false>();
+        hipLaunchKernelGGL((gj_panel_multi_kernel<16>), dim3(A.batch * A.ngroups), dim3(1024), lds, stream, A);
+        return hipSuccess;
+    }
     int nt, rpt;
     panel_geometry(p, p.np - A.row_lo, nt, rpt);
     const bool fused = A.upd_on != 0;
@@ -1089,6 +1195,11 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
             attr_set = true;
         }
     }
+    unsigned panel_launches = 0;  // tags of the multi-workgroup panels' exchange granules: unique per launch
+    if (p.multi_panel) {  // no stale tag of an earlier call may match
+        if ((e = hipMemsetAsync(ws.xch, 0, (size_t)kXchGranules * sizeof(unsigned long long) * batch, stream)) != hipSuccess)
+            return e;
+    }
     float *cur = ws.m0, *oth = ws.m1;
     bool pending_b = false;  // a (B) half is in flight on the second stream
     int blk = 0, ev = 0;
@@ -1127,6 +1238,10 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 P.orig = ws.orig;
                 P.aux_out = ws.aux[s & 1];
                 P.status = d_status;
+                const int prow = np - P.row_lo;  // rows the panel holds
+                P.ngroups = (p.multi_panel && prow > kPanelGroupRows) ? (prow + kPanelGroupRows - 1) / kPanelGroupRows : 1;
+                P.xch = ws.xch;
+                P.tag_base = ++panel_launches;
             }
             if (s > 0) {
                 const int t = s - 1;

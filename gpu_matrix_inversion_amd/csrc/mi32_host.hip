@@ -124,7 +124,7 @@ static BlockedPlan plan_blocked(const mi32_context *h, int n, int batch)
         const double elems = (double)batch * (double)n * (double)n;
         bw = (batch >= 8 && elems >= 64.0 * 1024.0 * 1024.0) ? 128 : 256;
     }
-    return make_blocked_plan(n, w, bw);
+    return make_blocked_plan(n, w, bw, batch);
 }
 static size_t ws_bytes_for(const mi32_context *h, int n, int batch, int algo)
 {

@@ -82,10 +82,13 @@ struct BlockedPlan {
     // as the elimination retires rows (16384 rows: 4, 8192: 8, 4096 and fewer: 16).
     int nblk;
     unsigned char wblk[128];
+    // more than 4096 candidate rows: the panel is shared by up to 4 workgroups instead of narrowing the
+    // sub-panels (small batches only: all of a panel's workgroups must be resident at the same time)
+    int multi_panel;
 };
 
 SweepPlan make_sweep_plan(int n);
-BlockedPlan make_blocked_plan(int n, int w, int bw);
+BlockedPlan make_blocked_plan(int n, int w, int bw, int batch);
 bool blocked_supported(int n);  // the register-resident panel holds at most 16384 (padded) rows
 
 size_t sweep_workspace_bytes(const SweepPlan &p, int batch);

@@ -273,17 +273,46 @@ def test_c1_single_4096_sweep_and_blocked_agree(inv_sweep, inv_blocked):
     assert rel < 1e-5, rel
 
 
-def test_blocked_4200_width_schedule_bit_identical_to_mirror(oracle, inv_blocked):
-    """N = 4200 pads to 4224 rows: while more than 4096 rows are candidates the panel kernel holds 8 rows
-    per lane and only W = 8 columns fit in registers; from the second outer block on W = 16."""
+def test_blocked_4200_two_workgroup_panel_bit_identical_to_mirror(oracle, inv_blocked):
+    """N = 4200 pads to 4224 rows: more than one workgroup holds at 4 rows per lane, so the first sub-panels
+    run on a panel shared by two workgroups (per-step exchange of the local winners through global memory);
+    the arithmetic is unchanged: bit-identical to the mirror with W = 16 everywhere."""
     n = 4200
     a = gate_matrix(n, 40_000)
     w, bw = inv_blocked.resolved_blocking(n, 1)
     widths = inv_blocked.resolved_panel_widths(n, 1)
-    assert (w, bw) == (16, 256) and widths[0] == 8 and set(widths[1:]) == {16} and len(widths) == 17
+    assert (w, bw) == (16, 256) and set(widths) == {16} and len(widths) == 17
     got, st = run(inv_blocked, a)
     want = oracle.matrix_inv_32_blocked2(a, n, widths, bw)
     assert st[0] == 0 and np.array_equal(got.reshape(-1), want)
+
+
+def test_blocked_4200_narrow_subpanel_schedule_bit_identical_to_mirror(oracle):
+    """The same matrix with the multi-workgroup panel off (a batch too large for it takes this path): while more
+    than 4096 rows are candidates the single panel workgroup holds 8 rows per lane and only W = 8 columns fit
+    in registers; from the second outer block on W = 16."""
+    n = 4200
+    a = gate_matrix(n, 40_000)
+    os.environ["MI32_MULTI_PANEL"] = "0"
+    try:
+        inv = g.Inverter(algo="blocked")
+        try:
+            widths = inv.resolved_panel_widths(n, 1)
+            assert widths[0] == 8 and set(widths[1:]) == {16} and len(widths) == 17
+            got, st = run(inv, a)
+            want = oracle.matrix_inv_32_blocked2(a, n, widths, inv.resolved_blocking(n, 1)[1])
+            assert st[0] == 0 and np.array_equal(got.reshape(-1), want)
+        finally:
+            inv.close()
+    finally:
+        del os.environ["MI32_MULTI_PANEL"]
+
+
+def test_three_workgroup_panel_8200(inv_blocked):
+    """N = 8200 (8320 padded rows): the first sub-panels are shared by three workgroups.  Too large for the
+    CPU oracle in a test: the size-independent exact properties and the residual gate instead."""
+    r = _full_size_properties(inv_blocked, 8200, 1, 50_000)
+    print("8200 (three-workgroup panel) residual", r)
 
 
 def test_sweep_2048_bit_identical_to_oracle(oracle, inv_sweep):
