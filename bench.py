@@ -214,7 +214,7 @@ def main():
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, x1024),
             # collected offline with rocprofv3 --pmc (separate passes) on this exact config
             traffic = None
-            pmc_path = os.path.join(ROOT, "profiles", "round1", "pmc_rank_bw_n4096.json")
+            pmc_path = os.path.join(ROOT, "profiles", "round1", "pmc_rank_bw2_n4096.json")
             if n == 4096 and batch == 1 and bw == 256 and os.path.exists(pmc_path):
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch_corrected")
             roof = {"bound": "mfma", "kernel": "gj_rank_bw2_kernel", "achieved": ach,
