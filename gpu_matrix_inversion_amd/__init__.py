@@ -15,12 +15,13 @@ from ._lib import (  # noqa: F401
     Mi32Error,
     build_library,
 )
-from .api import Inverter, just_inv, last_timing, matrix_inv_32, matrix_inv_32_batched  # noqa: F401
+from .api import Inverter, just_inv, last_timing, matrix_inv_32, matrix_inv_32_batched, matrix_inv_64  # noqa: F401
 from .sharding import invert_sharded, shard_range  # noqa: F401
 
 __all__ = [
     "matrix_inv_32",
     "matrix_inv_32_batched",
+    "matrix_inv_64",
     "just_inv",
     "last_timing",
     "Inverter",

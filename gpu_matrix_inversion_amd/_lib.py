@@ -44,6 +44,8 @@ C_ABI_SYMBOLS = (
     "mi32_get_profile",
     "mi32_last_timing",
     "mi32_resolve_algo",
+    "mi32_matrix_inv_64",
+    "mi32_inv_device_f64",
     "mi32_resolve_blocking",
     "mi32_resolve_panel_widths",
     "mi32_dominant_kernel",
@@ -52,6 +54,8 @@ C_ABI_SYMBOLS = (
 )
 # the C++ drop-in of include/mat_inv_32.h (Itanium-mangled matrix_inv_32(std::vector<float>, int))
 CXX_DROPIN_SYMBOL = "_Z13matrix_inv_32St6vectorIfSaIfEEi"
+# the fp64 twin of include/mat_inv_64.h: matrix_inversion_FP64(std::vector<double>, int)
+CXX_FP64_SYMBOL = "_Z21matrix_inversion_FP64St6vectorIdSaIdEEi"
 
 
 class Mi32Error(RuntimeError):
@@ -126,6 +130,11 @@ def load() -> ctypes.CDLL:
     lib.mi32_resolve_algo.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.mi32_resolve_blocking.restype = ctypes.c_int
     lib.mi32_resolve_blocking.argtypes = [vp, ctypes.c_int, ctypes.c_int, ip, ip]
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.mi32_matrix_inv_64.restype = ctypes.c_int
+    lib.mi32_matrix_inv_64.argtypes = [dp, ctypes.c_size_t, ctypes.c_int, dp]
+    lib.mi32_inv_device_f64.restype = ctypes.c_int
+    lib.mi32_inv_device_f64.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
     lib.mi32_resolve_panel_widths.restype = ctypes.c_int
     lib.mi32_resolve_panel_widths.argtypes = [vp, ctypes.c_int, ctypes.c_int, ip, ctypes.c_int, ip]
     lib.mi32_dominant_kernel.restype = ctypes.c_char_p

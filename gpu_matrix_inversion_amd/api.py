@@ -56,6 +56,26 @@ def matrix_inv_32(matrix_vector, matrix_order: int) -> np.ndarray:
     return np.empty(0, dtype=np.float32)
 
 
+def matrix_inv_64(matrix_vector, matrix_order: int) -> np.ndarray:
+    """Drop-in for the reference's ``matrix_inversion_FP64(std::vector<double>, int)`` (headers.h:9): flat
+    row-major float64 in, flat inverse out, empty array for a bad shape or a singular input."""
+    lib = _lib.load()
+    n = int(matrix_order)
+    v = np.ascontiguousarray(np.asarray(matrix_vector, dtype=np.float64).reshape(-1))
+    if n <= 0 or int(v.size // n) != n:
+        return np.empty(0, dtype=np.float64)
+    out = np.empty(n * n, dtype=np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib.mi32_matrix_inv_64(v.ctypes.data_as(dp), v.size, n, out.ctypes.data_as(dp))
+    if rc == MI32_OK:
+        return out
+    if rc == MI32_SINGULAR:
+        return out if os.environ.get("MI32_SINGULAR_KEEP", "0") not in ("", "0") else np.empty(0, dtype=np.float64)
+    if rc == _lib.MI32_RUNTIME_ERROR:
+        raise Mi32Error(lib.mi32_last_error().decode())
+    return np.empty(0, dtype=np.float64)
+
+
 def matrix_inv_32_batched(a: np.ndarray):
     """Host batch (B, N, N) -> (inverses (B, N, N), status int32[B])."""
     lib = _lib.load()
@@ -156,11 +176,11 @@ class Inverter:
         _lib.check(self._lib.mi32_reserve(self._h, int(n), int(batch)), "mi32_reserve")
 
     def inv(self, a, out=None, status=None):
-        """a: (N,N) or (B,N,N) float32 contiguous tensor on this device.  Asynchronous on
-        torch's current stream.  Returns (inverse, status int32[B] tensor)."""
+        """a: (N,N) or (B,N,N) float32 (or float64: the fp64 twin, sweep path) contiguous tensor on this
+        device.  Asynchronous on torch's current stream.  Returns (inverse, status int32[B] tensor)."""
         torch = self._torch
-        if a.dtype != torch.float32 or not a.is_cuda:
-            raise ValueError("expected a float32 tensor on the GPU")
+        if a.dtype not in (torch.float32, torch.float64) or not a.is_cuda:
+            raise ValueError("expected a float32 or float64 tensor on the GPU")
         squeeze = a.dim() == 2
         a3 = a.unsqueeze(0) if squeeze else a
         if a3.dim() != 3 or a3.shape[1] != a3.shape[2] or a3.shape[0] == 0 or a3.shape[1] == 0:
@@ -176,9 +196,9 @@ class Inverter:
         if status is None:
             status = torch.empty(b, dtype=torch.int32, device=a3.device)
         self._bind_stream()
-        _lib.check(self._lib.mi32_inv_device(self._h, ctypes.c_void_p(a3.data_ptr()), n, b,
-                                             ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(status.data_ptr())),
-                   "mi32_inv_device")
+        fn = self._lib.mi32_inv_device if a.dtype == torch.float32 else self._lib.mi32_inv_device_f64
+        _lib.check(fn(self._h, ctypes.c_void_p(a3.data_ptr()), n, b, ctypes.c_void_p(out.data_ptr()),
+                      ctypes.c_void_p(status.data_ptr())), "mi32_inv_device")
         return (out[0] if squeeze else out), status
 
     def set_lookahead(self, enable: bool):

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "mat_inv_32.h"
+#include "mat_inv_64.h"
 #include "mi32_internal.h"
 
 using namespace mi32;
@@ -80,7 +81,7 @@ struct mi32_context {
     // staging for the host-pointer entry points
     float *d_in = nullptr, *d_out = nullptr;
     int *d_status = nullptr;
-    size_t io_floats = 0, status_ints = 0;
+    size_t io_floats = 0, status_ints = 0;  // io_floats: capacity of d_in / d_out in 4-byte units
     std::mutex mu;
 };
 
@@ -128,7 +129,7 @@ static BlockedPlan plan_blocked(const mi32_context *h, int n, int batch)
 }
 static size_t ws_bytes_for(const mi32_context *h, int n, int batch, int algo)
 {
-    size_t a = (algo == MI32_ALGO_SWEEP) ? sweep_workspace_bytes(make_sweep_plan(n), batch)
+    size_t a = (algo == MI32_ALGO_SWEEP) ? sweep_workspace_bytes(make_sweep_plan(n), batch, sizeof(float))
                                          : blocked_workspace_bytes(plan_blocked(h, n, batch), batch);
     size_t r = residual_workspace_bytes(n, batch);
     return a > r ? a : r;
@@ -327,6 +328,19 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
     return MI32_OK;
 }
 
+int mi32_inv_device_f64(mi32_handle_t h, const double *d_a, int n, int batch, double *d_inv, int *d_status)
+{
+    if (!h || !d_a || !d_inv || n <= 0 || batch <= 0 || d_a == d_inv) return MI32_BAD_SHAPE;
+    std::lock_guard<std::mutex> lk(h->mu);
+    MI32_HIP(hipSetDevice(h->device));
+    const SweepPlan p = make_sweep_plan(n);
+    int rc = ensure_ws(h, sweep_workspace_bytes(p, batch, sizeof(double)));
+    if (rc != MI32_OK) return rc;
+    hipError_t e = sweep_invert_f64(p, d_a, d_inv, batch, d_status, h->ws, h->stream, h->prof);
+    if (e != hipSuccess) return fail(e, "kernel launch");
+    return MI32_OK;
+}
+
 int mi32_set_profiling(mi32_handle_t h, int enable)
 {
     if (!h) return MI32_BAD_SHAPE;
@@ -451,6 +465,40 @@ int mi32_matrix_inv_32(const float *a_rowmajor, size_t a_len, int n, float *inv_
     return mi32_matrix_inv_32_batched(a_rowmajor, n, 1, inv_rowmajor, nullptr);
 }
 
+int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor)
+{
+    // the guards of the fp32 library (mat_inv_32.cpp:206-215); matrix_inversion_FP64.cpp has the same two
+    if (n <= 0) return MI32_BAD_SHAPE;
+    if ((int)(a_len / (size_t)n) != n) return MI32_BAD_SHAPE;
+    if (!a_rowmajor || !inv_rowmajor) return MI32_BAD_SHAPE;
+    mi32_context *h = nullptr;
+    int rc = default_context(&h);
+    if (rc != MI32_OK) return rc;
+    static std::mutex call_mu;  // the staging buffers are shared with the fp32 host-pointer calls
+    std::lock_guard<std::mutex> lk(call_mu);
+    const auto t0 = std::chrono::steady_clock::now();
+    MI32_HIP(hipSetDevice(h->device));
+    const size_t elems = (size_t)n * n;
+    rc = ensure_io(h, 2 * elems, 1);  // doubles: two 4-byte units each
+    if (rc != MI32_OK) return rc;
+    double *din = reinterpret_cast<double *>(h->d_in), *dout = reinterpret_cast<double *>(h->d_out);
+    MI32_HIP(hipMemcpyAsync(din, a_rowmajor, elems * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    MI32_HIP(hipStreamSynchronize(h->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    rc = mi32_inv_device_f64(h, din, n, 1, dout, h->d_status);
+    if (rc != MI32_OK) return rc;
+    MI32_HIP(hipStreamSynchronize(h->stream));
+    const auto t2 = std::chrono::steady_clock::now();
+    int st = MI32_OK;
+    MI32_HIP(hipMemcpyAsync(&st, h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    MI32_HIP(hipMemcpyAsync(inv_rowmajor, dout, elems * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MI32_HIP(hipStreamSynchronize(h->stream));
+    const auto t3 = std::chrono::steady_clock::now();
+    g_last_total = std::chrono::duration<double>(t3 - t0).count();
+    g_last_compute = std::chrono::duration<double>(t2 - t1).count();
+    return st;
+}
+
 int mi32_last_timing(double *total_seconds, double *compute_seconds)
 {
     if (total_seconds) *total_seconds = g_last_total;
@@ -473,5 +521,19 @@ std::vector<float> matrix_inv_32(std::vector<float> matrix_vector, int matrix_or
     // returns the inf/NaN result instead, as the shipped library does.
     if (rc == MI32_SINGULAR && env_int("MI32_SINGULAR_KEEP", 0)) return result;
     if (rc == MI32_RUNTIME_ERROR) std::fprintf(stderr, "matrix_inv_32: %s\n", mi32_last_error());
+    return {};
+}
+
+// ---- the reference's fp64 entry point, unchanged signature (matrix_inversion/headers.h:9) ----
+std::vector<double> matrix_inversion_FP64(std::vector<double> matrix_vector, int matrix_order)
+{
+    if (matrix_order <= 0) return {};
+    if ((int)(matrix_vector.size() / (size_t)matrix_order) != matrix_order) return {};
+    std::vector<double> result((size_t)matrix_order * matrix_order, 0.0);
+    const int rc = mi32_matrix_inv_64(matrix_vector.data(), matrix_vector.size(), matrix_order, result.data());
+    if (rc == MI32_OK) return result;
+    // a singular input: {} like the reference (its exact-identity check, matrix_inversion_FP64.cpp:846-867)
+    if (rc == MI32_SINGULAR && env_int("MI32_SINGULAR_KEEP", 0)) return result;
+    if (rc == MI32_RUNTIME_ERROR) std::fprintf(stderr, "matrix_inversion_FP64: %s\n", mi32_last_error());
     return {};
 }

@@ -91,13 +91,16 @@ SweepPlan make_sweep_plan(int n);
 BlockedPlan make_blocked_plan(int n, int w, int bw, int batch);
 bool blocked_supported(int n);  // the register-resident panel holds at most 16384 (padded) rows
 
-size_t sweep_workspace_bytes(const SweepPlan &p, int batch);
+size_t sweep_workspace_bytes(const SweepPlan &p, int batch, size_t elem_bytes);
 size_t blocked_workspace_bytes(const BlockedPlan &p, int batch);
 
 // Enqueue a whole inversion on `stream`.  ws: workspace of at least the size
 // reported above, 256-byte aligned.
 hipError_t sweep_invert(const SweepPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *ws,
                         hipStream_t stream, Profiler *prof);
+// the fp64 twin (matrix_inversion_FP64 of the reference): same launches on doubles
+hipError_t sweep_invert_f64(const SweepPlan &p, const double *d_a, double *d_inv, int batch, int *d_status, void *ws,
+                            hipStream_t stream, Profiler *prof);
 // streams/events a blocked inversion is enqueued with: `aux` (may be null) carries the look-ahead half
 // of each rank-bw update; events[0 .. n/2) mark "second-stream work done", events[n/2 .. n) "panel phase done"
 struct BlockedExec {

@@ -28,9 +28,66 @@
 //      multipliers as fixColumnKernel does (mat_inv_32.cpp:28)
 //   4. the one thread that owns column r+1 keeps the arg-max of the values it
 //      just produced and leaves the record for the next launch.
+//
+// The whole path is a template on the element type: float is the library's matrix_inv_32, double the
+// reference's second precision (matrix_inversion_FP64, matrix_inversion_FP64.cpp:13 -- the same five kernels
+// in double, kernels :18-206): same launches, 16 N^2 bytes per step.
 #include "mi32_internal.h"
 
 namespace mi32 {
+
+// four consecutive elements of a row: one 16-byte (float) or two 16-byte (double) accesses
+template <typename T>
+struct __attribute__((aligned(4 * sizeof(T)))) Vec4 {
+    T x, y, z, w;
+};
+
+// arg-max record of one candidate: {bits(|a|), ~row} under an unsigned lexicographic order (largest |a|, lowest
+// row among equal maxima, NaN never wins; see pivot_key in mi32_internal.h).  float: one 64-bit word.
+// double: |a| alone has 63 significant bits, so the record is two words.
+template <typename T>
+struct PivotRec;
+template <>
+struct PivotRec<float> {
+    unsigned long long k;
+    __device__ static PivotRec none() { return PivotRec{0ull}; }
+    __device__ static PivotRec make(float a, int row) { return PivotRec{pivot_key(a, row)}; }
+    __device__ bool beats(const PivotRec &o) const { return k > o.k; }
+    __device__ int row(int fallback) const { return pivot_key_row(k, fallback); }
+    __device__ PivotRec shfl_xor(int off) const { return PivotRec{(unsigned long long)__shfl_xor(k, off, 64)}; }
+};
+template <>
+struct PivotRec<double> {
+    unsigned long long v, nrow;  // bits(|a|), ~row; {0, 0} = no candidate
+    __device__ static PivotRec none() { return PivotRec{0ull, 0ull}; }
+    __device__ static PivotRec make(double a, int row)
+    {
+        const double m = __builtin_fabs(a);
+        if (!(m == m)) return none();
+        return PivotRec{(unsigned long long)__double_as_longlong(m), (unsigned long long)(0xFFFFFFFFu - (unsigned)row)};
+    }
+    __device__ bool beats(const PivotRec &o) const { return v > o.v || (v == o.v && nrow > o.nrow); }
+    __device__ int row(int fallback) const
+    {
+        return (v == 0ull && nrow == 0ull) ? fallback : (int)(0xFFFFFFFFu - (unsigned)nrow);
+    }
+    __device__ PivotRec shfl_xor(int off) const
+    {
+        return PivotRec{(unsigned long long)__shfl_xor(v, off, 64), (unsigned long long)__shfl_xor(nrow, off, 64)};
+    }
+};
+template <typename T>
+__device__ __forceinline__ PivotRec<T> wave_max_rec(PivotRec<T> k)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const PivotRec<T> o = k.shfl_xor(off);
+        k = o.beats(k) ? o : k;
+    }
+    return k;
+}
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 static constexpr int kSweepThreads = 256;
 static constexpr int kColsPerTile = kSweepThreads * 4;
@@ -52,25 +109,25 @@ SweepPlan make_sweep_plan(int n)
 // workspace: [W0][W1][keys0][keys1][orig][invp], each region 256-B aligned
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct SweepWs {
-    float *w0, *w1;
-    unsigned long long *k0, *k1;
+    void *w0, *w1;   // the two working copies (element type T)
+    void *k0, *k1;   // per-row-tile arg-max records (PivotRec<T>)
     int *orig, *invp;
-    size_t wstride;  // floats per matrix
+    size_t wstride;  // elements per matrix
 };
-static size_t sweep_carve(const SweepPlan &p, int batch, void *base, SweepWs *o)
+static size_t sweep_carve(const SweepPlan &p, int batch, void *base, SweepWs *o, size_t elem_bytes)
 {
-    const size_t wbytes = align256((size_t)p.n * p.ld * sizeof(float));
-    const size_t kbytes = align256((size_t)p.row_tiles * sizeof(unsigned long long) * batch);
+    const size_t wbytes = align256((size_t)p.n * p.ld * elem_bytes);
+    const size_t kbytes = align256((size_t)p.row_tiles * 2 * sizeof(unsigned long long) * batch);
     const size_t ibytes = align256((size_t)p.n * sizeof(int) * batch);
     char *c = (char *)base;
     size_t off = 0;
-    if (o) { o->w0 = (float *)(c + off); o->wstride = wbytes / sizeof(float); }
+    if (o) { o->w0 = (void *)(c + off); o->wstride = wbytes / elem_bytes; }
     off += wbytes * batch;
-    if (o) o->w1 = (float *)(c + off);
+    if (o) o->w1 = (void *)(c + off);
     off += wbytes * batch;
-    if (o) o->k0 = (unsigned long long *)(c + off);
+    if (o) o->k0 = (void *)(c + off);
     off += kbytes;
-    if (o) o->k1 = (unsigned long long *)(c + off);
+    if (o) o->k1 = (void *)(c + off);
     off += kbytes;
     if (o) o->orig = (int *)(c + off);
     off += ibytes;
@@ -78,38 +135,41 @@ static size_t sweep_carve(const SweepPlan &p, int batch, void *base, SweepWs *o)
     off += ibytes;
     return off;
 }
-size_t sweep_workspace_bytes(const SweepPlan &p, int batch) { return sweep_carve(p, batch, nullptr, nullptr); }
+size_t sweep_workspace_bytes(const SweepPlan &p, int batch, size_t elem_bytes)
+{
+    return sweep_carve(p, batch, nullptr, nullptr, elem_bytes);
+}
 
 // ---- makeAugmentedMatrix counterpart (mat_inv_32.cpp:177-192) ---------------
 // Copies A into the first working copy (the identity half is implicit) and
 // leaves the arg-max records of column 0 for step 0.
-template <int TR>
-__global__ __launch_bounds__(kSweepThreads) void sweep_init_kernel(const float *__restrict__ in, int n, int ld,
-                                                                    size_t wstride, float *__restrict__ w0,
-                                                                    unsigned long long *__restrict__ keys, int npart,
+template <typename T, int TR>
+__global__ __launch_bounds__(kSweepThreads) void sweep_init_kernel(const T *__restrict__ in, int n, int ld,
+                                                                    size_t wstride, T *__restrict__ w0,
+                                                                    PivotRec<T> *__restrict__ keys, int npart,
                                                                     int *__restrict__ orig, int *__restrict__ status)
 {
     const int b = blockIdx.z;
     const int tid = threadIdx.x;
     const int j4 = (blockIdx.x * kSweepThreads + tid) * 4;
     const int row0 = blockIdx.y * TR;
-    const float *a = in + (size_t)b * n * n;
-    float *w = w0 + (size_t)b * wstride;
-    unsigned long long best = 0ull;
+    const T *a = in + (size_t)b * n * n;
+    T *w = w0 + (size_t)b * wstride;
+    PivotRec<T> best = PivotRec<T>::none();
     if (j4 < ld) {
 #pragma unroll 4
         for (int u = 0; u < TR; ++u) {
             const int i = row0 + u;
             if (i >= n) break;
-            float4 v;
-            v.x = (j4 + 0 < n) ? a[(size_t)i * n + j4 + 0] : 0.0f;
-            v.y = (j4 + 1 < n) ? a[(size_t)i * n + j4 + 1] : 0.0f;
-            v.z = (j4 + 2 < n) ? a[(size_t)i * n + j4 + 2] : 0.0f;
-            v.w = (j4 + 3 < n) ? a[(size_t)i * n + j4 + 3] : 0.0f;
-            *reinterpret_cast<float4 *>(w + (size_t)i * ld + j4) = v;
+            Vec4<T> v;
+            v.x = (j4 + 0 < n) ? a[(size_t)i * n + j4 + 0] : T(0);
+            v.y = (j4 + 1 < n) ? a[(size_t)i * n + j4 + 1] : T(0);
+            v.z = (j4 + 2 < n) ? a[(size_t)i * n + j4 + 2] : T(0);
+            v.w = (j4 + 3 < n) ? a[(size_t)i * n + j4 + 3] : T(0);
+            *reinterpret_cast<Vec4<T> *>(w + (size_t)i * ld + j4) = v;
             if (j4 == 0) {
-                const unsigned long long k = pivot_key(v.x, i);
-                best = k > best ? k : best;
+                const PivotRec<T> k = PivotRec<T>::make(v.x, i);
+                best = k.beats(best) ? k : best;
             }
         }
     }
@@ -122,17 +182,20 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_init_kernel(const float *
 }
 
 // ---- one pivot step ---------------------------------------------------------
-__device__ __forceinline__ float4 fma4_neg(float f, float4 a, float4 c)
+template <typename T>
+__device__ __forceinline__ Vec4<T> fma4_neg(T f, Vec4<T> a, Vec4<T> c)
 {
-    float4 o;
-    o.x = __builtin_fmaf(-f, a.x, c.x);
-    o.y = __builtin_fmaf(-f, a.y, c.y);
-    o.z = __builtin_fmaf(-f, a.z, c.z);
-    o.w = __builtin_fmaf(-f, a.w, c.w);
+    Vec4<T> o;
+    o.x = fma_t(-f, a.x, c.x);
+    o.y = fma_t(-f, a.y, c.y);
+    o.z = fma_t(-f, a.z, c.z);
+    o.w = fma_t(-f, a.w, c.w);
     return o;
 }
-__device__ __forceinline__ float comp(const float4 &v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
-__device__ __forceinline__ void set_comp(float4 &v, int c, float x)
+template <typename T>
+__device__ __forceinline__ T comp(const Vec4<T> &v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+template <typename T>
+__device__ __forceinline__ void set_comp(Vec4<T> &v, int c, T x)
 {
     if (c == 0) v.x = x;
     else if (c == 1) v.y = x;
@@ -140,37 +203,37 @@ __device__ __forceinline__ void set_comp(float4 &v, int c, float x)
     else v.w = x;
 }
 
-template <int TR>
-__global__ __launch_bounds__(kSweepThreads) void gj_sweep_step_kernel(const float *__restrict__ src_all,
-                                                                       float *__restrict__ dst_all, int n, int ld,
+template <typename T, int TR>
+__global__ __launch_bounds__(kSweepThreads) void gj_sweep_step_kernel(const T *__restrict__ src_all,
+                                                                       T *__restrict__ dst_all, int n, int ld,
                                                                        size_t wstride, int r,
-                                                                       const unsigned long long *__restrict__ keys_in,
-                                                                       unsigned long long *__restrict__ keys_out,
+                                                                       const PivotRec<T> *__restrict__ keys_in,
+                                                                       PivotRec<T> *__restrict__ keys_out,
                                                                        int npart, int *__restrict__ orig,
                                                                        int *__restrict__ status)
 {
-    __shared__ unsigned long long s_key[kSweepThreads / 64];
+    __shared__ PivotRec<T> s_key[kSweepThreads / 64];
     const int b = blockIdx.z;
     const int tid = threadIdx.x;
-    const float *src = src_all + (size_t)b * wstride;
-    float *dst = dst_all + (size_t)b * wstride;
+    const T *src = src_all + (size_t)b * wstride;
+    T *dst = dst_all + (size_t)b * wstride;
 
     // 1. finalMaxPivot: reduce the per-row-tile records of column r
-    unsigned long long k = 0ull;
+    PivotRec<T> k = PivotRec<T>::none();
     for (int t = tid; t < npart; t += kSweepThreads) {
-        const unsigned long long o = keys_in[(size_t)b * npart + t];
-        k = o > k ? o : k;
+        const PivotRec<T> o = keys_in[(size_t)b * npart + t];
+        k = o.beats(k) ? o : k;
     }
-    k = wave_max_u64(k);
+    k = wave_max_rec<T>(k);
     if ((tid & 63) == 0) s_key[tid >> 6] = k;
     __syncthreads();
     {
-        const unsigned long long a = s_key[0] > s_key[1] ? s_key[0] : s_key[1];
-        const unsigned long long c = s_key[2] > s_key[3] ? s_key[2] : s_key[3];
-        k = a > c ? a : c;
+        const PivotRec<T> a = s_key[0].beats(s_key[1]) ? s_key[0] : s_key[1];
+        const PivotRec<T> c = s_key[2].beats(s_key[3]) ? s_key[2] : s_key[3];
+        k = a.beats(c) ? a : c;
     }
-    const int p = pivot_key_row(k, r);
-    const float piv = src[(size_t)p * ld + r];  // read before the swap, as mat_inv_32.cpp:70,129-130
+    const int p = k.row(r);
+    const T piv = src[(size_t)p * ld + r];  // read before the swap, as mat_inv_32.cpp:70,129-130
 
     const int j4 = (blockIdx.x * kSweepThreads + tid) * 4;
     const bool active = j4 < ld;
@@ -181,47 +244,47 @@ __global__ __launch_bounds__(kSweepThreads) void gj_sweep_step_kernel(const floa
     const int row0 = blockIdx.y * TR;
 
     // 2. fixRow: the normalised pivot row slice (IEEE division), identity entry -> 1/piv
-    float4 prn = make_float4(0.f, 0.f, 0.f, 0.f);
+    const Vec4<T> zero4 = {T(0), T(0), T(0), T(0)};
+    Vec4<T> prn = zero4;
     if (active) {
-        const float4 pr = *reinterpret_cast<const float4 *>(src + (size_t)p * ld + j4);
+        const Vec4<T> pr = *reinterpret_cast<const Vec4<T> *>(src + (size_t)p * ld + j4);
         prn.x = pr.x / piv;
         prn.y = pr.y / piv;
         prn.z = pr.z / piv;
         prn.w = pr.w / piv;
-        if (has_r) set_comp(prn, rc, 1.0f / piv);
+        if (has_r) set_comp<T>(prn, rc, T(1) / piv);
     }
 
     // 3. pivotElements + fixColumn over this workgroup's rows
-    unsigned long long best = 0ull;
+    PivotRec<T> best = PivotRec<T>::none();
 #pragma unroll
     for (int u0 = 0; u0 < TR; u0 += 4) {
-        float f[4];
-        float4 v[4];
+        T f[4];
+        Vec4<T> v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = row0 + u0 + u;
             const int s = (i == p) ? r : i;  // slot p receives the old row r
             const bool ok = (i < n);
-            f[u] = ok ? src[(size_t)s * ld + r] : 0.0f;
-            v[u] = (ok && active) ? *reinterpret_cast<const float4 *>(src + (size_t)s * ld + j4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            f[u] = ok ? src[(size_t)s * ld + r] : T(0);
+            v[u] = (ok && active) ? *reinterpret_cast<const Vec4<T> *>(src + (size_t)s * ld + j4) : zero4;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = row0 + u0 + u;
             if (i >= n || !active) continue;
-            float4 o;
+            Vec4<T> o;
             if (i == r) {
                 o = prn;
             } else {
                 o = v[u];
-                if (has_r) set_comp(o, rc, 0.0f);  // the implicit identity column's entry in this row
-                if (f[u] != 0.0f) o = fma4_neg(f[u], prn, o);
+                if (has_r) set_comp<T>(o, rc, T(0));  // the implicit identity column's entry in this row
+                if (f[u] != T(0)) o = fma4_neg<T>(f[u], prn, o);
             }
-            *reinterpret_cast<float4 *>(dst + (size_t)i * ld + j4) = o;
+            *reinterpret_cast<Vec4<T> *>(dst + (size_t)i * ld + j4) = o;
             if (has_next && i > r) {
-                const unsigned long long kk = pivot_key(comp(o, nc), i);
-                best = kk > best ? kk : best;
+                const PivotRec<T> kk = PivotRec<T>::make(comp<T>(o, nc), i);
+                best = kk.beats(best) ? kk : best;
             }
         }
     }
@@ -235,7 +298,7 @@ __global__ __launch_bounds__(kSweepThreads) void gj_sweep_step_kernel(const floa
             og[r] = og[p];
             og[p] = t;
         }
-        if (status && (piv == 0.0f || piv != piv)) status[b] = MI32_SINGULAR;
+        if (status && (piv == T(0) || piv != piv)) status[b] = MI32_SINGULAR;
     }
 }
 
@@ -249,15 +312,16 @@ __global__ void invert_perm_kernel(const int *__restrict__ orig, int *__restrict
     if (c < n) invp[(size_t)b * n + orig[(size_t)b * n + c]] = c;
 }
 
-__global__ __launch_bounds__(256) void unpermute_columns_kernel(const float *__restrict__ w_all, int ld, size_t wstride,
+template <typename T>
+__global__ __launch_bounds__(256) void unpermute_columns_kernel(const T *__restrict__ w_all, int ld, size_t wstride,
                                                                  const int *__restrict__ invp, int n,
-                                                                 float *__restrict__ out)
+                                                                 T *__restrict__ out)
 {
     const int b = blockIdx.z;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const float *w = w_all + (size_t)b * wstride;
-    float *o = out + (size_t)b * n * n;
+    const T *w = w_all + (size_t)b * wstride;
+    T *o = out + (size_t)b * n * n;
     const int c = invp[(size_t)b * n + j];
     const int i0 = blockIdx.y * 16;
 #pragma unroll 4
@@ -267,44 +331,57 @@ __global__ __launch_bounds__(256) void unpermute_columns_kernel(const float *__r
     }
 }
 
-template <int TR>
-static hipError_t sweep_run(const SweepPlan &p, const float *d_a, float *d_inv, int batch, int *d_status,
-                            const SweepWs &ws, hipStream_t stream, Profiler *prof)
+template <typename T, int TR>
+static hipError_t sweep_run(const SweepPlan &p, const T *d_a, T *d_inv, int batch, int *d_status, const SweepWs &ws,
+                            hipStream_t stream, Profiler *prof)
 {
     const dim3 grid(p.col_tiles, p.row_tiles, batch);
     const dim3 block(kSweepThreads);
+    T *w0 = (T *)ws.w0, *w1 = (T *)ws.w1;
+    PivotRec<T> *k0 = (PivotRec<T> *)ws.k0, *k1 = (PivotRec<T> *)ws.k1;
     {
         ProfScope ps(prof, KC_INIT, stream);
-        hipLaunchKernelGGL(sweep_init_kernel<TR>, grid, block, 0, stream, d_a, p.n, p.ld, ws.wstride, ws.w0, ws.k0,
+        hipLaunchKernelGGL((sweep_init_kernel<T, TR>), grid, block, 0, stream, d_a, p.n, p.ld, ws.wstride, w0, k0,
                            p.row_tiles, ws.orig, d_status);
     }
     for (int r = 0; r < p.n; ++r) {
         const bool even = (r % 2) == 0;
         ProfScope ps(prof, KC_SWEEP_STEP, stream);
-        hipLaunchKernelGGL(gj_sweep_step_kernel<TR>, grid, block, 0, stream, even ? ws.w0 : ws.w1,
-                           even ? ws.w1 : ws.w0, p.n, p.ld, ws.wstride, r, even ? ws.k0 : ws.k1,
-                           even ? ws.k1 : ws.k0, p.row_tiles, ws.orig, d_status);
+        hipLaunchKernelGGL((gj_sweep_step_kernel<T, TR>), grid, block, 0, stream, even ? w0 : w1, even ? w1 : w0, p.n,
+                           p.ld, ws.wstride, r, even ? k0 : k1, even ? k1 : k0, p.row_tiles, ws.orig, d_status);
     }
-    const float *fin = (p.n % 2 == 0) ? ws.w0 : ws.w1;  // the last-written copy (mat_inv_32.cpp:369-372)
+    const T *fin = (p.n % 2 == 0) ? w0 : w1;  // the last-written copy (mat_inv_32.cpp:369-372)
     ProfScope ps(prof, KC_FINISH, stream);
     hipLaunchKernelGGL(invert_perm_kernel, dim3((p.n + 255) / 256, batch), dim3(256), 0, stream, ws.orig, ws.invp,
                        p.n);
-    hipLaunchKernelGGL(unpermute_columns_kernel, dim3((p.n + 255) / 256, (p.n + 15) / 16, batch), dim3(256), 0,
+    hipLaunchKernelGGL((unpermute_columns_kernel<T>), dim3((p.n + 255) / 256, (p.n + 15) / 16, batch), dim3(256), 0,
                        stream, fin, p.ld, ws.wstride, ws.invp, p.n, d_inv);
     return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t sweep_invert_t(const SweepPlan &p, const T *d_a, T *d_inv, int batch, int *d_status, void *wsp,
+                                 hipStream_t stream, Profiler *prof)
+{
+    SweepWs ws;
+    sweep_carve(p, batch, wsp, &ws, sizeof(T));
+    switch (p.tr) {
+        case 4: return sweep_run<T, 4>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
+        case 8: return sweep_run<T, 8>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
+        case 16: return sweep_run<T, 16>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
+        default: return sweep_run<T, 32>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
+    }
 }
 
 hipError_t sweep_invert(const SweepPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *wsp,
                         hipStream_t stream, Profiler *prof)
 {
-    SweepWs ws;
-    sweep_carve(p, batch, wsp, &ws);
-    switch (p.tr) {
-        case 4: return sweep_run<4>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
-        case 8: return sweep_run<8>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
-        case 16: return sweep_run<16>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
-        default: return sweep_run<32>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
-    }
+    return sweep_invert_t<float>(p, d_a, d_inv, batch, d_status, wsp, stream, prof);
+}
+hipError_t sweep_invert_f64(const SweepPlan &p, const double *d_a, double *d_inv, int batch, int *d_status, void *wsp,
+                            hipStream_t stream, Profiler *prof)
+{
+    return sweep_invert_t<double>(p, d_a, d_inv, batch, d_status, wsp, stream, prof);
 }
 
 }  // namespace mi32

@@ -85,6 +85,13 @@ int mi32_reserve(mi32_handle_t h, int n, int batch);
  * of mat_inv_32.cpp:292-376 (makeAugmented -> N pivot steps -> getInverted). */
 int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *d_inv, int *d_status);
 
+/* ---- fp64 (the reference's matrix_inversion_FP64, matrix_inversion/headers.h:9) ---------------- */
+/* Same Gauss-Jordan step sequence in double, on the sweep path (one fused launch per pivot step, HBM-bound:
+ * 16 N (N+1) bytes per step); bit-identical to the oracle's fp64 restatement.  Host-pointer twin of the C++
+ * function in mat_inv_64.h, and the device-resident batched form (asynchronous on the context's stream). */
+int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor);
+int mi32_inv_device_f64(mi32_handle_t h, const double *d_a, int n, int batch, double *d_inv, int *d_status);
+
 /* Device-side verification (the reference's matrix_multiply.cpp:17-36,193-200 and
  * the residual BASELINE.json gates): per matrix, d_out[3*b+0] = ||A X - I||_inf,
  * d_out[3*b+1] = ||X A - I||_inf, d_out[3*b+2] = sqrt(N) - ||A X||_F, all

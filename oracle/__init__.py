@@ -24,6 +24,7 @@ from .oracle import (  # noqa: F401
     matrix_inv_32_blocked,
     matrix_inv_32_blocked2,
     matrix_inv_32_inplace,
+    matrix_inv_64,
     msvc_rand_stream,
     numpy_mirror_inv,
     residual_inf,

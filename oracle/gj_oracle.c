@@ -281,6 +281,61 @@ int gjo_matrix_inv_32_inplace(const float *in, size_t in_len, int n, float *out,
     return status;
 }
 
+/* ---- fp64 twin ----------------------------------------------------------- */
+/* The reference's matrix_inversion_FP64 (matrix_inversion_FP64.cpp:13; kernels :18-206, host loop as in the
+ * fp32 library) is the same five-kernel step in double; here the in-place N x N form of it with true partial
+ * pivoting (largest |a|, lowest row among equals), IEEE division and one fused multiply-add per element
+ * (exact-zero multipliers skipped, matrix_inversion_FP64.cpp:28). */
+int gjo_matrix_inv_64_inplace(const double *in, size_t in_len, int n, double *out, int *pivots)
+{
+    if (!shape_ok(in_len, n)) return GJO_BAD_SHAPE;
+    const size_t ld = (size_t)n;
+    double *m = (double *)malloc(sizeof(double) * ld * n);
+    int *orig = (int *)malloc(sizeof(int) * n);
+    double *rowr = (double *)malloc(sizeof(double) * n);
+    if (!m || !orig || !rowr) {
+        free(m); free(orig); free(rowr);
+        return GJO_BAD_SHAPE;
+    }
+    memcpy(m, in, sizeof(double) * ld * n);
+    for (int i = 0; i < n; ++i) orig[i] = i;
+    int status = GJO_OK;
+    for (int r = 0; r < n; ++r) {
+        int p = r;
+        double best = -1.0;
+        for (int i = r; i < n; ++i) {
+            const double v = fabs(m[(size_t)i * ld + r]);
+            if (v > best) { best = v; p = i; } /* NaN never wins, the first maximum is kept */
+        }
+        const double piv = m[(size_t)p * ld + r];
+        if (pivots) pivots[r] = p;
+        if (piv == 0.0 || piv != piv) status = GJO_SINGULAR;
+        if (p != r) {
+            for (int j = 0; j < n; ++j) {
+                double t = m[(size_t)r * ld + j];
+                m[(size_t)r * ld + j] = m[(size_t)p * ld + j];
+                m[(size_t)p * ld + j] = t;
+            }
+            int t = orig[r]; orig[r] = orig[p]; orig[p] = t;
+        }
+        for (int j = 0; j < n; ++j) m[(size_t)r * ld + j] = m[(size_t)r * ld + j] / piv;
+        m[(size_t)r * ld + r] = 1.0 / piv;
+        memcpy(rowr, m + (size_t)r * ld, sizeof(double) * n);
+        for (int i = 0; i < n; ++i) {
+            if (i == r) continue;
+            double *mi = m + (size_t)i * ld;
+            const double cir = mi[r];
+            mi[r] = 0.0;
+            if (cir != 0.0)
+                for (int j = 0; j < n; ++j) mi[j] = fma(-cir, rowr[j], mi[j]);
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < n; ++c) out[(size_t)i * n + orig[c]] = m[(size_t)i * ld + c];
+    free(m); free(orig); free(rowr);
+    return status;
+}
+
 /* ---- blocked restatement (CPU mirror of the HIP blocked path) ---------- */
 /* In-place Gauss-Jordan on column blocks of width w: the N x w panel is
  * reduced with the unblocked steps above (pivot search over the whole column

@@ -70,6 +70,10 @@ int gjo_matrix_inv_32(const float *in, size_t in_len, int n, float *out,
 int gjo_matrix_inv_32_inplace(const float *in, size_t in_len, int n, float *out,
                               int arith_mode, int *pivots);
 
+/* fp64 twin of the in-place form (the reference's matrix_inversion_FP64, matrix_inversion_FP64.cpp:13), with
+ * true partial pivoting and one fma per element. */
+int gjo_matrix_inv_64_inplace(const double *in, size_t in_len, int n, double *out, int *pivots);
+
 /* Blocked (rank-b delayed update) restatement of the same elimination: the
  * CPU mirror of the HIP blocked path's operation order (panel of width w
  * factored with partial pivoting, then one rank-w update of every other

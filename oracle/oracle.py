@@ -65,6 +65,9 @@ def _load():
     lib.gjo_matrix_inv_32_blocked.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ctypes.c_int, ip]
     lib.gjo_matrix_inv_32_blocked2.restype = ctypes.c_int
     lib.gjo_matrix_inv_32_blocked2.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, ip]
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.gjo_matrix_inv_64_inplace.restype = ctypes.c_int
+    lib.gjo_matrix_inv_64_inplace.argtypes = [dp, ctypes.c_size_t, ctypes.c_int, dp, ip]
     lib.gjo_matrix_inv_32_blocked2w.restype = ctypes.c_int
     lib.gjo_matrix_inv_32_blocked2w.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ip, ctypes.c_int, ctypes.c_int, ip]
     for nm in ("gjo_residual_inf", "gjo_residual_inf_left", "gjo_frobenius_metric"):
@@ -120,6 +123,24 @@ def matrix_inv_32_inplace(vec, n: int, arith_mode: int = ARITH_FMA, return_info:
     out = np.empty(n * n, dtype=np.float32)
     piv = np.empty(n, dtype=np.int32)
     st = lib.gjo_matrix_inv_32_inplace(_fp(v), v.size, n, _fp(out), arith_mode,
+                                       piv.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if return_info:
+        return out, {"status": st, "pivots": piv}
+    return out
+
+
+def matrix_inv_64(vec, n: int, return_info: bool = False):
+    """fp64 twin (the reference's matrix_inversion_FP64 call shape): flat row-major in, flat inverse out."""
+    lib = _load()
+    v = np.ascontiguousarray(np.asarray(vec, dtype=np.float64).reshape(-1))
+    n = int(n)
+    if n <= 0 or int(v.size // n) != n:
+        empty = np.empty(0, dtype=np.float64)
+        return (empty, {"status": STATUS_BAD_SHAPE}) if return_info else empty
+    out = np.empty(n * n, dtype=np.float64)
+    piv = np.empty(n, dtype=np.int32)
+    dp = ctypes.POINTER(ctypes.c_double)
+    st = lib.gjo_matrix_inv_64_inplace(v.ctypes.data_as(dp), v.size, n, out.ctypes.data_as(dp),
                                        piv.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
     if return_info:
         return out, {"status": st, "pivots": piv}

@@ -42,6 +42,10 @@ def test_every_declared_symbol_is_exported():
     assert getattr(lib, _lib.CXX_DROPIN_SYMBOL) is not None
     out = subprocess.run(["c++filt", _lib.CXX_DROPIN_SYMBOL], capture_output=True, text=True).stdout.strip()
     assert out == "matrix_inv_32(std::vector<float, std::allocator<float> >, int)"
+    # std::vector<double> matrix_inversion_FP64(std::vector<double>, int) -- include/mat_inv_64.h (headers.h:9)
+    assert getattr(lib, _lib.CXX_FP64_SYMBOL) is not None
+    out = subprocess.run(["c++filt", _lib.CXX_FP64_SYMBOL], capture_output=True, text=True).stdout.strip()
+    assert out == "matrix_inversion_FP64(std::vector<double, std::allocator<double> >, int)"
 
 
 def test_dropin_header_matches_reference_declaration():
@@ -71,6 +75,7 @@ def test_shape_guards_need_no_gpu():
     assert g.matrix_inv_32(np.ones(3), 2).size == 0
     assert g.matrix_inv_32(np.ones(6), 2).size == 0
     assert g.matrix_inv_32(np.zeros(0), 3).size == 0
+    assert g.matrix_inv_64(np.ones(6), 2).size == 0 and g.matrix_inv_64(np.ones(4), -1).size == 0
 
 
 def test_workspace_sizes():

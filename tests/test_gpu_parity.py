@@ -209,6 +209,34 @@ def test_nan_input_is_flagged_not_chosen(inv_sweep, inv_blocked):
         assert st[0] == 2
 
 
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 100, 257, 700])
+def test_fp64_sweep_bit_identical_to_fp64_oracle(oracle, inv_sweep, n):
+    """The fp64 twin (matrix_inversion_FP64 of the reference): same launches on doubles, bit-identical to the
+    oracle's fp64 restatement; device-resident (torch.float64) and through the host-pointer C ABI."""
+    for kind in ("gate", "ref100", "hollow"):
+        if kind == "hollow" and n == 1:
+            continue
+        a = dist_matrix(kind, n, 9000 + n).astype(np.float64)
+        want, info = oracle.matrix_inv_64(a, n, return_info=True)
+        ta = torch.from_numpy(a).cuda()
+        x, st = inv_sweep.inv(ta)
+        torch.cuda.synchronize()
+        assert int(st[0]) == info["status"] == 0
+        assert np.array_equal(x.cpu().numpy().reshape(-1), want), (kind, n)
+    got = g.matrix_inv_64(a.reshape(-1), n)
+    assert got.dtype == np.float64 and np.array_equal(got, want)
+    assert g.matrix_inv_64(np.ones((4, 4)).reshape(-1), 4).size == 0   # singular -> empty, like the reference
+
+
+def test_fp64_1024_residual(inv_sweep):
+    n = 1024
+    a = torch.from_numpy(gate_matrix(n, 60_000).astype(np.float64)).cuda()
+    x, st = inv_sweep.inv(a)
+    torch.cuda.synchronize()
+    res = float((a @ x - torch.eye(n, dtype=torch.float64, device="cuda")).abs().sum(dim=1).max())
+    assert int(st[0]) == 0 and res < 1e-11, res
+
+
 def test_device_residual_matches_oracle(oracle, inv_blocked):
     n = 300
     a = dist_matrix("ref100", n, 5)

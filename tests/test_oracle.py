@@ -140,3 +140,23 @@ def test_metrics_on_known_case(oracle):
     bad = np.array([[0.5, 0.1], [0, 0.25]], np.float32)
     assert oracle.residual_inf(a, bad, 2) == pytest.approx(0.2, rel=1e-6)
     assert oracle.residual_inf_left(a, bad, 2) == pytest.approx(0.4, rel=1e-6)
+
+
+def test_fp64_twin_against_numpy_and_fp32_oracle():
+    """gjo_matrix_inv_64_inplace (the reference's matrix_inversion_FP64 restated): agrees with
+    numpy.linalg.inv to fp64 Gauss-Jordan accuracy, makes the same pivot choices as the fp32 oracle on
+    the same (fp32-representable) input, and keeps the reference's guards."""
+    import oracle as O
+
+    for n, seed in ((1, 1), (5, 2), (64, 3), (100, 4), (257, 5)):
+        rng = np.random.default_rng(seed)
+        a = (rng.uniform(-1, 1, (n, n)) + np.sqrt(n) * np.eye(n))[rng.permutation(n)].astype(np.float32)
+        x64, info64 = O.matrix_inv_64(a.astype(np.float64), n, return_info=True)
+        _, info32 = O.matrix_inv_32_inplace(a, n, return_info=True)
+        assert info64["status"] == 0
+        want = np.linalg.inv(a.astype(np.float64))
+        assert np.abs(x64.reshape(n, n) - want).max() / np.abs(want).max() < 1e-12
+        assert np.array_equal(info64["pivots"], info32["pivots"])
+    assert O.matrix_inv_64(np.ones(6), 2).size == 0 and O.matrix_inv_64(np.ones(4), 0).size == 0
+    _, info = O.matrix_inv_64(np.ones((4, 4)), 4, return_info=True)
+    assert info["status"] == O.STATUS_SINGULAR
