@@ -1114,9 +1114,9 @@ static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelA
         hipLaunchKernelGGL((gj_panel_multi_kernel<16>), dim3(A.batch * A.ngroups), dim3(1024), lds, stream, A);
         return hipSuccess;
     }
+    const bool fused = A.upd_on != 0;
     int nt, rpt;
     panel_geometry(p, p.np - A.row_lo, nt, rpt);
-    const bool fused = A.upd_on != 0;
     const int nwgs = A.batch + A.batch * (tiles / (nt / 256));
 #define MI32_SUBPANEL_CASE(T, R, WW)                                                                   \
     if (nt == T && rpt == R && w == WW && !fused) return launch_subpanel<T, R, WW, false>(A, nwgs, stream);

@@ -14,38 +14,6 @@
 
 using namespace mi32;
 
-// experiment: persistent workgroups (RB_PERSIST per CU), each walks the tiles with stride gridDim.x; a one-time
-// start stagger keeps the workgroups that share a CU out of phase.  RB_SLOTMAP 0: slot = block / 256 (the
-// dispatcher fills one workgroup per CU per pass), 1: slot = (block / 8) % RB_PERSIST.
-#ifndef RB_PERSIST
-#define RB_PERSIST 4
-#endif
-#ifndef RB_STAGGER
-#define RB_STAGGER 0
-#endif
-#ifndef RB_SLOTMAP
-#define RB_SLOTMAP 0
-#endif
-template <int BK, int WPS>
-__global__ __launch_bounds__(256, WPS) void rank_bw2_persist_stagger_kernel(
-    const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
-    const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
-    const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int nbatch)
-{
-    extern __shared__ __attribute__((aligned(16))) float rb_smem[];
-    const int T = np / 128;
-    const int slot = RB_SLOTMAP == 0 ? (int)(blockIdx.x / 256) : (int)((blockIdx.x / 8) % RB_PERSIST);
-    for (int i = 0; i < slot * RB_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    for (long id = blockIdx.x; id < (long)T * T * nbatch; id += gridDim.x) {
-        const int b = (int)(id / (T * T));
-        int rt, ct;
-        rb_tile_of((int)(id % (T * T)), T, rt, ct);
-        rank_bw2_tile<BK>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
-                          copy_panel, ex, tstride, 0, 0, b, rt, ct, rb_smem);
-        __syncthreads();
-    }
-}
-
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 #ifndef RB_BK
@@ -107,11 +75,6 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL((gj_rank_bw2_kernel<RB_BK, RB_WPS>), dim3(T * T, batch), dim3(256), lds2, 0, src, d2, g, mstride, gk,
                            gkstride, np, ld, mstride, c0, kdim, map, 1, PanelExport{pt2, 0, pt_col, pt_w, 1}, tstride, 0, 0);
     };
-    CK(hipFuncSetAttribute((const void *)rank_bw2_persist_stagger_kernel<RB_BK, RB_WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    auto run3 = [&]() {
-        hipLaunchKernelGGL((rank_bw2_persist_stagger_kernel<RB_BK, RB_WPS>), dim3(256 * RB_PERSIST), dim3(256), lds2, 0, src, d2, g,
-                           mstride, gk, gkstride, np, ld, mstride, c0, kdim, map, 1, PanelExport{pt2, 0, pt_col, pt_w, 1}, tstride, batch);
-    };
     run1(); runT(); run2();
     CK(hipDeviceSynchronize());
     CK(hipGetLastError());
@@ -143,7 +106,5 @@ int main(int argc, char **argv)
     time_it("gen2 transpose", runT);
     time_it("gen2 update", run2);
     time_it("gen2 transpose+update", [&]() { runT(); run2(); });
-    printf("persistent: %d per CU, stagger %d x 3.4 us, slot map %d\n", RB_PERSIST, RB_STAGGER, RB_SLOTMAP);
-    time_it("gen2 persistent+stagger", run3);
     return bad != 0 || !pt_same;
 }
