@@ -336,6 +336,18 @@ def test_blocked_4200_narrow_subpanel_schedule_bit_identical_to_mirror(oracle):
         del os.environ["MI32_MULTI_PANEL"]
 
 
+def test_blocked_2300_unfused_then_fused_blocks_bit_identical_to_mirror(oracle, inv_blocked):
+    """N = 2300 (2304 padded rows): the first outer block still has more than 2048 candidate rows (panel and
+    in-block update as separate launches), every later block runs the fused launches -- both modes and the
+    hand-over between them in one inversion, bit-identical to the mirror."""
+    n = 2300
+    a = dist_matrix("ref100", n, 41_000)
+    widths = inv_blocked.resolved_panel_widths(n, 1)
+    got, st = run(inv_blocked, a)
+    want = oracle.matrix_inv_32_blocked2(a, n, widths, inv_blocked.resolved_blocking(n, 1)[1])
+    assert st[0] == 0 and np.array_equal(got.reshape(-1), want)
+
+
 def test_three_workgroup_panel_8200(inv_blocked):
     """N = 8200 (8320 padded rows): the first sub-panels are shared by three workgroups.  Too large for the
     CPU oracle in a test: the size-independent exact properties and the residual gate instead."""
