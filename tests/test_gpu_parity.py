@@ -366,3 +366,21 @@ def test_sweep_2048_bit_identical_to_oracle(oracle, inv_sweep):
 def test_c2_batch_of_2048(inv_blocked):
     r = _full_size_properties(inv_blocked, 2048, 8, 30_000)
     print("C2 (8 of the 64) residual", r)
+
+
+def test_c4_single_16384_maximum_size(inv_blocked):
+    """C4 = the largest order the blocked path takes (four-workgroup panel for the first 12288 pivots).  The fp64
+    residual product is done by torch (checker only, 8.8 TFLOP); plus the exact power-of-two scaling property."""
+    n = 16384
+    a = torch.from_numpy(gate_matrix(n, 70_000)).cuda()
+    x, st = inv_blocked.inv(a)
+    x2, st2 = inv_blocked.inv(a * 2.0)
+    torch.cuda.synchronize()
+    assert int(st[0]) == 0 and int(st2[0]) == 0
+    assert torch.equal(x2 * 2.0, x)
+    del x2
+    r = a.double() @ x.double()
+    r.diagonal().sub_(1.0)
+    res = float(r.abs().sum(dim=1).max())
+    print("C4 residual", res)
+    assert res < 1e-3, res
