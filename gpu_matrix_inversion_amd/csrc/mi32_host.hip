@@ -67,7 +67,8 @@ struct mi32_context {
     int device = 0;
     EventProfiler *prof = nullptr;
     hipEvent_t switch_event = nullptr;
-    hipStream_t aux_stream = nullptr;   // look-ahead half of the rank-bw updates
+    hipStream_t aux_stream = nullptr;   // look-ahead half of the rank-bw updates (lowest priority)
+    hipStream_t split_stream = nullptr; // second half of a split batch (same priority as the main stream)
     hipEvent_t la_events[8] = {};
     int aux_workgroups = 0;
     bool lookahead = true;
@@ -129,8 +130,15 @@ static BlockedPlan plan_blocked(const mi32_context *h, int n, int batch)
 }
 static size_t ws_bytes_for(const mi32_context *h, int n, int batch, int algo)
 {
-    size_t a = (algo == MI32_ALGO_SWEEP) ? sweep_workspace_bytes(make_sweep_plan(n), batch, sizeof(float))
-                                         : blocked_workspace_bytes(plan_blocked(h, n, batch), batch);
+    size_t a;
+    if (algo == MI32_ALGO_SWEEP) a = sweep_workspace_bytes(make_sweep_plan(n), batch, sizeof(float));
+    else {
+        const BlockedPlan p = plan_blocked(h, n, batch);
+        // a batch that may be split in two halves (mi32_inv_device) carves one workspace per half
+        a = blocked_workspace_bytes(p, (batch + 1) / 2) + blocked_workspace_bytes(p, batch - (batch + 1) / 2);
+        const size_t whole = blocked_workspace_bytes(p, batch);
+        if (whole > a) a = whole;
+    }
     size_t r = residual_workspace_bytes(n, batch);
     return a > r ? a : r;
 }
@@ -141,6 +149,7 @@ static int ensure_ws(mi32_context *h, size_t bytes)
     if (h->ws) {
         MI32_HIP(hipStreamSynchronize(h->stream));
         if (h->aux_stream) MI32_HIP(hipStreamSynchronize(h->aux_stream));
+        if (h->split_stream) MI32_HIP(hipStreamSynchronize(h->split_stream));
         MI32_HIP(hipFree(h->ws));
         h->ws = nullptr;
         h->ws_bytes = 0;
@@ -193,6 +202,7 @@ int mi32_create(mi32_handle_t *out, int device)
         MI32_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         MI32_HIP(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_low));
         for (auto &ev : h->la_events) MI32_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        MI32_HIP(hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
     }
     *out = h;
     return MI32_OK;
@@ -212,6 +222,10 @@ int mi32_destroy(mi32_handle_t h)
     if (h->aux_stream) {
         (void)hipStreamSynchronize(h->aux_stream);
         (void)hipStreamDestroy(h->aux_stream);
+    }
+    if (h->split_stream) {
+        (void)hipStreamSynchronize(h->split_stream);
+        (void)hipStreamDestroy(h->split_stream);
     }
     for (auto ev : h->la_events)
         if (ev) (void)hipEventDestroy(ev);
@@ -303,6 +317,16 @@ int mi32_reserve(mi32_handle_t h, int n, int batch)
     return ensure_ws(h, ws_bytes_for(h, n, batch, resolve_algo(h, n)));
 }
 
+// A GPU-filling batch of the blocked path is run as two halves on the context's two streams: the MFMA-bound
+// rank-bw launches of one half overlap the latency / HBM-bound sub-panel launches of the other (64 x 2048^2:
+// 18.5 -> 17.4 ms; three or four parts lose).  Both halves use the blocking of the whole batch, so a matrix's
+// result does not depend on the split; mi32_set_lookahead(h, 0) turns the second stream off altogether.
+static bool split_batch(const mi32_context *h, int algo, int n, int batch)
+{
+    return algo == MI32_ALGO_BLOCKED && h->lookahead && h->split_stream != nullptr && batch >= 16 &&
+           (double)batch * n * n >= 64.0 * 1024.0 * 1024.0 && env_int("MI32_BATCH_SPLIT", 1) != 0;
+}
+
 int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *d_inv, int *d_status)
 {
     if (!h || !d_a || !d_inv || n <= 0 || batch <= 0 || d_a == d_inv) return MI32_BAD_SHAPE;
@@ -322,7 +346,27 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
         ex.n_events = h->aux_stream ? 8 : 0;
         ex.aux_workgroups = h->aux_workgroups;
         ex.prof = h->prof;
-        e = blocked_invert(plan_blocked(h, n, batch), d_a, d_inv, batch, d_status, h->ws, ex);
+        const BlockedPlan p = plan_blocked(h, n, batch);
+        if (!split_batch(h, algo, n, batch)) {
+            e = blocked_invert(p, d_a, d_inv, batch, d_status, h->ws, ex);
+        } else {
+            const int b0 = (batch + 1) / 2, b1 = batch - b0;
+            const size_t mat = (size_t)n * n;
+            char *ws1 = (char *)h->ws + blocked_workspace_bytes(p, b0);  // ws_bytes_for reserved both parts
+            // the second stream joins here and is joined again at the end (events 0 and 1 are free: the
+            // look-ahead, their other user, only runs for single matrices)
+            MI32_HIP(hipEventRecord(h->la_events[0], h->stream));
+            MI32_HIP(hipStreamWaitEvent(h->split_stream, h->la_events[0], 0));
+            BlockedExec ex0 = ex, ex1 = ex;
+            ex0.aux = ex1.aux = nullptr;
+            ex1.stream = h->split_stream;
+            e = blocked_invert(p, d_a, d_inv, b0, d_status, h->ws, ex0);
+            if (e == hipSuccess)
+                e = blocked_invert(p, d_a + (size_t)b0 * mat, d_inv + (size_t)b0 * mat, b1,
+                                   d_status ? d_status + b0 : nullptr, ws1, ex1);
+            MI32_HIP(hipEventRecord(h->la_events[1], h->split_stream));
+            MI32_HIP(hipStreamWaitEvent(h->stream, h->la_events[1], 0));
+        }
     }
     if (e != hipSuccess) return fail(e, "kernel launch");
     return MI32_OK;

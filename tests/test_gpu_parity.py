@@ -368,6 +368,30 @@ def test_c2_batch_of_2048(inv_blocked):
     print("C2 (8 of the 64) residual", r)
 
 
+def test_split_batch_is_bit_identical_to_the_unsplit_batch(inv_blocked):
+    """A GPU-filling batch runs as two halves on two streams (both with the blocking of the whole batch): every
+    matrix's inverse and status must be exactly what the single-stream run gives, odd batch sizes included."""
+    n, B = 1024, 67   # 67 x 1024^2 elements >= 64 Mi: split into 34 + 33
+    mats = torch.from_numpy(np.stack([gate_matrix(n, 80_000 + b) for b in range(B)])).cuda()
+    mats[5] = 1.0     # one singular member, in the first half
+    mats[60] = 0.0    # and one in the second
+    x_split, st_split = inv_blocked.inv(mats)
+    torch.cuda.synchronize()
+    os.environ["MI32_BATCH_SPLIT"] = "0"
+    try:
+        x_one, st_one = inv_blocked.inv(mats)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["MI32_BATCH_SPLIT"]
+    want = [0] * B
+    want[5] = want[60] = 2
+    assert st_split.tolist() == want and st_one.tolist() == want
+    ok = [b for b in range(B) if b not in (5, 60)]
+    assert torch.equal(x_split[ok], x_one[ok])
+    r = inv_blocked.residual(mats[ok], x_split[ok])
+    assert float(r[:, 0].max()) < 1e-3
+
+
 def test_c4_single_16384_maximum_size(inv_blocked):
     """C4 = the largest order the blocked path takes (four-workgroup panel for the first 12288 pivots).  The fp64
     residual product is done by torch (checker only, 8.8 TFLOP); plus the exact power-of-two scaling property."""
