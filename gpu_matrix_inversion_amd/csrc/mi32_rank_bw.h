@@ -110,6 +110,19 @@ __device__ __forceinline__ void rb_tile_of(int id, int T, int &rt, int &ct)
     }
 }
 
+// Diagnostic builds (tools/rank_bw_bench.hip, -DMI32_RB_STAMPS) record s_memtime at the phase boundaries of
+// every workgroup; in the product build the macro expands to nothing.
+#ifdef MI32_RB_STAMPS
+__device__ unsigned long long *g_rb_stamps;  // [workgroup][8]
+#define MI32_RB_STAMP(slot_)                                                                          \
+    do {                                                                                              \
+        if (g_rb_stamps && threadIdx.x == 0)                                                          \
+            g_rb_stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot_)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define MI32_RB_STAMP(slot_) do { } while (0)
+#endif
+
 // One 128 x 128 output tile (rt, ct) of matrix b.  rb_smem: rank_bw2_lds_bytes<BK>(kdim) bytes of LDS.
 template <int BK>
 __device__ __forceinline__ void rank_bw2_tile(
@@ -148,6 +161,7 @@ __device__ __forceinline__ void rank_bw2_tile(
         return;
     }
 
+    MI32_RB_STAMP(0);
     if (tid < BM) s_map[tid] = map[row0 + tid];
     for (int i = tid; i < kdim; i += 256) s_bmap[i] = map[c0 + i];
     __syncthreads();
@@ -176,6 +190,7 @@ __device__ __forceinline__ void rank_bw2_tile(
     const int lhalf = lane >> 5;
     const int nk = kdim / BK;
     const bool tile_in_block = (row0 >= c0 && row0 < c0 + kdim);
+    MI32_RB_STAMP(1);
     MI32_RB_ISSUE(0, 0)
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
@@ -207,6 +222,7 @@ __device__ __forceinline__ void rank_bw2_tile(
         }
     }
 #undef MI32_RB_ISSUE
+    MI32_RB_STAMP(2);
 
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -237,8 +253,16 @@ __device__ __forceinline__ void rank_bw2_tile(
                 panel_export_store4(ex, tstride, b, np, col, row0 + wr * 64 + tm * 32 + 8 * q + 4 * lhalf, cv[4 * q],
                                     cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
         }
+    MI32_RB_STAMP(3);
+#ifdef MI32_RB_STAMPS
+    if (g_rb_stamps && threadIdx.x == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_rb_stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 4] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
-
 
 template <int BK, int WPS>
 __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(

@@ -14,6 +14,9 @@
 
 using namespace mi32;
 
+#ifdef MI32_RB_STAMPS
+__global__ void set_stamp_buffer(unsigned long long *p) { mi32::g_rb_stamps = p; }
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 #ifndef RB_BK
@@ -102,6 +105,32 @@ int main(int argc, char **argv)
         const double us = ms * 1000.0 / reps;
         printf("%-28s %9.2f us  %7.1f TFLOP/s\n", name, us, flops / us * 1e-6);
     };
+#ifdef MI32_RB_STAMPS
+    {   // per-workgroup phase stamps of ONE gen2 launch -> per-CU timeline statistics
+        const size_t nwg = (size_t)T * T * batch;
+        unsigned long long *dst_stamps;
+        CK(hipMalloc(&dst_stamps, nwg * 8 * 8));
+        CK(hipMemset(dst_stamps, 0, nwg * 8 * 8));
+        hipLaunchKernelGGL(set_stamp_buffer, dim3(1), dim3(1), 0, 0, dst_stamps);
+        CK(hipDeviceSynchronize());
+        run2(); run2();
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> st(nwg * 8);
+        CK(hipMemcpy(st.data(), dst_stamps, st.size() * 8, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(set_stamp_buffer, dim3(1), dim3(1), 0, 0, (unsigned long long *)nullptr);
+        CK(hipDeviceSynchronize());
+        FILE *f = fopen("gpurun_out/rb_stamps.csv", "w");
+        if (f) {
+            fprintf(f, "wg,t0,t1,t2,t3,hwid,xcc\n");
+            for (size_t i = 0; i < nwg; ++i)
+                if (st[i * 8 + 3])
+                    fprintf(f, "%zu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, st[i * 8], st[i * 8 + 1], st[i * 8 + 2], st[i * 8 + 3],
+                            st[i * 8 + 4] & 0xffffffffull, st[i * 8 + 4] >> 32);
+            fclose(f);
+        }
+        printf("stamps written for %zu workgroups\n", nwg);
+    }
+#endif
     time_it("gen1 update", run1);
     time_it("gen2 transpose", runT);
     time_it("gen2 update", run2);
