@@ -90,23 +90,23 @@ __device__ __forceinline__ void rb_glds16(const float *gsrc, float *lds_wave_bas
 
 // LDS footprint of one workgroup of gj_rank_bw2_kernel<BK>: two stages of (A tile + B tile), the C-row
 // map of the tile and the pivot-row map of the block.
-template <int BK>
+template <int BK, int BN = 128>
 constexpr size_t rank_bw2_lds_bytes(int kdim)
 {
-    return (size_t)(2 * 2 * BK * 128) * sizeof(float) + (size_t)(128 + kdim) * sizeof(int);
+    return (size_t)(2 * BK * (128 + BN)) * sizeof(float) + (size_t)(128 + kdim) * sizeof(int);
 }
 
 // XCD-aware tile order (see mi32_blocked.hip): workgroups that share an XCD cover a compact sub-grid.
-__device__ __forceinline__ void rb_tile_of(int id, int T, int &rt, int &ct)
+__device__ __forceinline__ void rb_tile_of(int id, int TR, int TC, int &rt, int &ct)
 {
-    if ((T & 7) == 0) {
+    if ((TR & 1) == 0 && (TC & 3) == 0) {
         const int xcd = id & 7, idx = id >> 3;
-        const int tr = T / 2, tc = T / 4;
+        const int tr = TR / 2, tc = TC / 4;
         rt = (xcd >> 2) * tr + idx / tc;
         ct = (xcd & 3) * tc + idx % tc;
     } else {
-        rt = id / T;
-        ct = id % T;
+        rt = id / TC;
+        ct = id % TC;
     }
 }
 
@@ -123,19 +123,24 @@ __device__ unsigned long long *g_rb_stamps;  // [workgroup][8]
 #define MI32_RB_STAMP(slot_) do { } while (0)
 #endif
 
-// One 128 x 128 output tile (rt, ct) of matrix b.  rb_smem: rank_bw2_lds_bytes<BK>(kdim) bytes of LDS.
-template <int BK>
+// One 128 x BN output tile (rt, ct) of matrix b (BN = 128 or 64: 4 waves as 2 x 2, 64 x BN/2 each).
+// rb_smem: rank_bw2_lds_bytes<BK, BN>(kdim) bytes of LDS.
+template <int BK, int BN = 128>
 __device__ __forceinline__ void rank_bw2_tile(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
     const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
     const int *__restrict__ map_all, int copy_panel, const PanelExport &ex, size_t tstride, int skip_lo, int skip_hi,
     int b, int rt, int ct, float *rb_smem)
 {
-    constexpr int BM = 128, BN = 128;
-    constexpr int ND = BK / 8;  // LDS-DMA instructions per wave per operand per stage (each moves 2 k-rows)
+    constexpr int BM = 128;
+    constexpr int TN = BN / 64;          // 32-column MFMA tiles per wave
+    constexpr int ND = BK / 8;           // LDS-DMA instructions per wave per stage for A (each moves 2 k-rows)
+    constexpr int NDB = BK * BN / 1024;  // ... for B (each moves 256 / BN k-rows)
+    constexpr int KPB = 256 / BN;        // k-rows of B per LDS-DMA instruction
+    static_assert(NDB >= 1, "B tile smaller than one LDS-DMA per wave");
     float *s_a = rb_smem;                    // [2][BK][128]
-    float *s_b = rb_smem + 2 * BK * 128;     // [2][BK][128]
-    int *s_map = reinterpret_cast<int *>(rb_smem + 4 * BK * 128);  // [128]  C rows of this tile
+    float *s_b = rb_smem + 2 * BK * 128;     // [2][BK][BN]
+    int *s_map = reinterpret_cast<int *>(rb_smem + 2 * BK * (128 + BN));  // [128]  C rows of this tile
     int *s_bmap = s_map + 128;               // [kdim] pivot rows of the block
 
     const int tid = threadIdx.x;
@@ -168,21 +173,25 @@ __device__ __forceinline__ void rank_bw2_tile(
 
     // per-lane source addresses of this wave's DMA slices: k-rows 2*(wave*ND + i) + (lane >> 5) of a stage
     const int lk = lane >> 5, lc4 = (lane & 31) * 4;
+    const int lkb = lane / (BN / 4), lcb4 = (lane % (BN / 4)) * 4;  // B: k-row and column inside one LDS-DMA
     const float *a_src = gk + (size_t)lk * np + row0 + lc4;  // + (kt + 2 * (wave * ND + i)) * np
-    const float *b_col = src + col0 + lc4;                   // + s_bmap[kt + 2 * (wave * ND + i) + lk] * ld
+    const float *b_col = src + col0 + lcb4;                  // + s_bmap[kt + KPB * (wave * NDB + i) + lkb] * ld
 
 #define MI32_RB_ISSUE(STAGE, KT)                                                                       \
     _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                   \
         const int kr = 2 * (wave * ND + i);                                                            \
         rb_glds16(a_src + (size_t)((KT) + kr) * np, s_a + ((STAGE) * BK + kr) * 128);                  \
-        rb_glds16(b_col + (size_t)s_bmap[(KT) + kr + lk] * ld, s_b + ((STAGE) * BK + kr) * 128);       \
+    }                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NDB; ++i) {                                                  \
+        const int kr = KPB * (wave * NDB + i);                                                         \
+        rb_glds16(b_col + (size_t)s_bmap[(KT) + kr + lkb] * ld, s_b + ((STAGE) * BK + kr) * BN);       \
     }
 
-    rb_float16v acc[2][2];
+    rb_float16v acc[2][TN];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) acc[tm][tn][reg] = 0.0f;
 
@@ -200,25 +209,29 @@ __device__ __forceinline__ void rank_bw2_tile(
         __builtin_amdgcn_s_barrier();
         if (t + 1 < nk) { MI32_RB_ISSUE(buf ^ 1, (t + 1) * BK) }
         const float *pa = s_a + buf * BK * 128 + lhalf * 128 + wr * 64 + lcol;
-        const float *pb = s_b + buf * BK * 128 + lhalf * 128 + wc * 64 + lcol;
-        float af[2], bf[2];
+        const float *pb = s_b + buf * BK * BN + lhalf * BN + wc * (BN / 2) + lcol;
+        float af[2], bf[TN];
         af[0] = pa[0]; af[1] = pa[32];
-        bf[0] = pb[0]; bf[1] = pb[32];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bf[tn] = pb[tn * 32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float afn[2] = {0.f, 0.f}, bfn[2] = {0.f, 0.f};
+            float afn[2] = {0.f, 0.f}, bfn[TN] = {};
             if (kk + 2 < BK) {
                 afn[0] = pa[(kk + 2) * 128]; afn[1] = pa[(kk + 2) * 128 + 32];
-                bfn[0] = pb[(kk + 2) * 128]; bfn[1] = pb[(kk + 2) * 128 + 32];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bfn[tn] = pb[(kk + 2) * BN + tn * 32];
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ABOVE this pair's MFMAs
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) { af[q] = afn[q]; bf[q] = bfn[q]; }
+            for (int q = 0; q < 2; ++q) af[q] = afn[q];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = bfn[tn];
         }
     }
 #undef MI32_RB_ISSUE
@@ -227,8 +240,8 @@ __device__ __forceinline__ void rank_bw2_tile(
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = col0 + wc * 64 + tn * 32 + lcol;
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = col0 + wc * (BN / 2) + tn * 32 + lcol;
             // the old values C (row-mapped); the rows of the block itself start from 0.  Block bounds are
             // multiples of 128, so a whole tile is either inside the block or outside it.
             float cv[16];
@@ -264,7 +277,7 @@ __device__ __forceinline__ void rank_bw2_tile(
 #endif
 }
 
-template <int BK, int WPS>
+template <int BK, int WPS, int BN = 128>
 __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
     const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
@@ -272,9 +285,9 @@ __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) float rb_smem[];
     int rt, ct;
-    rb_tile_of(blockIdx.x, np / 128, rt, ct);
-    rank_bw2_tile<BK>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all, copy_panel,
-                      ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
+    rb_tile_of(blockIdx.x, np / 128, np / BN, rt, ct);
+    rank_bw2_tile<BK, BN>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
+                          copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
 }
 
 // Persistent, residency-limited flavour for the look-ahead half (see blocked_invert): gridDim.x workgroups
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
     const int T = np / 128;
     for (int id = blockIdx.x; id < T * T; id += gridDim.x) {
         int rt, ct;
-        rb_tile_of(id, T, rt, ct);
+        rb_tile_of(id, T, T, rt, ct);
         rank_bw2_tile<BK>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
                           copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
         __syncthreads();  // the next tile re-uses the LDS buffers and maps

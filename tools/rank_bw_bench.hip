@@ -25,6 +25,9 @@ __global__ void set_stamp_buffer(unsigned long long *p) { mi32::g_rb_stamps = p;
 #ifndef RB_WPS
 #define RB_WPS 3
 #endif
+#ifndef RB_BN
+#define RB_BN 128
+#endif
 
 int main(int argc, char **argv)
 {
@@ -37,7 +40,7 @@ int main(int argc, char **argv)
     const size_t mstride = (size_t)np * ld;
     const size_t gkstride = (size_t)kdim * np;
     const size_t tstride = (size_t)32 * np;
-    printf("rank-bw bench: np=%d kdim=%d batch=%d c0=%d BK=%d WPS=%d\n", np, kdim, batch, c0, RB_BK, RB_WPS);
+    printf("rank-bw bench: np=%d kdim=%d batch=%d c0=%d BK=%d WPS=%d BN=%d\n", np, kdim, batch, c0, RB_BK, RB_WPS, RB_BN);
 
     std::vector<float> h(mstride * batch);
     srand(3);
@@ -64,8 +67,8 @@ int main(int argc, char **argv)
 
     const int T = np / 128;
     const int pt_col = c0 + kdim, pt_w = 16;
-    const size_t lds2 = rank_bw2_lds_bytes<RB_BK>(kdim);
-    CK(hipFuncSetAttribute((const void *)gj_rank_bw2_kernel<RB_BK, RB_WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    const size_t lds2 = rank_bw2_lds_bytes<RB_BK, RB_BN>(kdim);
+    CK(hipFuncSetAttribute((const void *)gj_rank_bw2_kernel<RB_BK, RB_WPS, RB_BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     auto run1 = [&]() {
         hipLaunchKernelGGL((gj_rank_bw_update_kernel<16, 3>), dim3(T * T, batch), dim3(256), 0, 0, src, d1, g, mstride, np, ld,
                            mstride, c0, kdim, map, 1, pt1, tstride, pt_col, pt_w, 0, 0);
@@ -75,7 +78,7 @@ int main(int argc, char **argv)
                            gkstride);
     };
     auto run2 = [&]() {
-        hipLaunchKernelGGL((gj_rank_bw2_kernel<RB_BK, RB_WPS>), dim3(T * T, batch), dim3(256), lds2, 0, src, d2, g, mstride, gk,
+        hipLaunchKernelGGL((gj_rank_bw2_kernel<RB_BK, RB_WPS, RB_BN>), dim3(T * (np / RB_BN), batch), dim3(256), lds2, 0, src, d2, g, mstride, gk,
                            gkstride, np, ld, mstride, c0, kdim, map, 1, PanelExport{pt2, 0, pt_col, pt_w, 1}, tstride, 0, 0);
     };
     run1(); runT(); run2();
