@@ -151,6 +151,7 @@ def test_cxx_dropin_links_and_runs(oracle, tmp_path):
 #include <cstdio>
 #include <vector>
 #include "mat_inv_32.h"
+#include "mat_inv_64.h"
 int main() {
     const int n = 3;
     std::vector<float> a = {2, 1, 0,  1, 3, 1,  0, 1, 4};
@@ -161,6 +162,12 @@ int main() {
     std::vector<float> neg = matrix_inv_32(a, -1);
     std::vector<float> sing = matrix_inv_32(std::vector<float>(16, 1.0f), 4);
     std::printf("sizes %zu %zu %zu\n", bad.size(), neg.size(), sing.size());
+    // the fp64 twin, by the reference's own name (matrix_inversion/headers.h:9)
+    std::vector<double> ad(a.begin(), a.end());
+    std::vector<double> xd = matrix_inversion_FP64(ad, n);
+    if (xd.size() != 9) { std::printf("EMPTY64\n"); return 1; }
+    for (double v : xd) std::printf("%.17g\n", v);
+    std::printf("sizes64 %zu %zu\n", matrix_inversion_FP64(ad, 2).size(), matrix_inv_64(std::vector<double>(16, 1.0), 4).size());
     return 0;
 }
 ''')
@@ -176,6 +183,9 @@ int main() {
     got = np.array([float(v) for v in lines[:9]], np.float32)
     assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
     assert lines[9] == "sizes 0 0 0"
+    got64 = np.array([float(v) for v in lines[10:19]], np.float64)
+    assert np.array_equal(got64, oracle.matrix_inv_64(a.astype(np.float64), 3))
+    assert lines[19] == "sizes64 0 0"
 
 
 def test_batched_with_a_singular_member(oracle, inv_sweep, inv_blocked):
