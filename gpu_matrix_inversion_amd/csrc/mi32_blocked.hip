@@ -1293,12 +1293,13 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 if ((e = hipStreamWaitEvent(stream, ex.events[ev], 0)) != hipSuccess) return e;
                 pending_b = false;
             }
-            {   // A operand of the rank-bw update: the block's panel, k-major (mi32_rank_bw.h)
+            const bool split_update = lookahead && has_next;
+            if (!split_update) {  // A operand of the rank-bw update: the block's panel, k-major (mi32_rank_bw.h)
                 ProfScope ps(prof, KC_TRANSPOSE, stream);
                 hipLaunchKernelGGL(gj_panel_transpose_kernel, dim3(np / 64, kb / 64, batch), dim3(256), 0, stream, x,
                                    ws.mstride, np, p.ld, C0, ws.gk, ws.gkstride);
             }
-            if (lookahead && has_next) {
+            if (split_update) {
                 {   // (A): the next block's columns, on the main stream; exports the next sub-panels
                     ProfScope ps(prof, KC_UPDATE_OUT, stream);
                     // small tiles: only kb_next columns, so 64x64 gives 4x the workgroups of 128x128
@@ -1311,6 +1312,11 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 hipEvent_t e_panel = ex.events[ex.n_events / 2 + ev];
                 if ((e = hipEventRecord(e_panel, stream)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(ex.aux, e_panel, 0)) != hipSuccess) return e;
+                {   // only half (B) reads the transposed panel: its transposition stays off the main stream
+                    ProfScope ps(prof, KC_TRANSPOSE, ex.aux);
+                    hipLaunchKernelGGL(gj_panel_transpose_kernel, dim3(np / 64, kb / 64, batch), dim3(256), 0, ex.aux, x,
+                                       ws.mstride, np, p.ld, C0, ws.gk, ws.gkstride);
+                }
                 {
                     ProfScope ps(prof, KC_UPDATE_OUT, ex.aux);
                     // persistent flavour: aux_workgroups (< number of CUs) workgroups, with so much dynamic LDS
