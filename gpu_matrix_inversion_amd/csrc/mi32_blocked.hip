@@ -958,6 +958,7 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     __shared__ float s_a[BK * LDA];
     __shared__ __attribute__((aligned(16))) float s_b[BK * LDB];
     __shared__ int s_map[BM];
+    __shared__ int s_bmap[kMaxBW];  // the block's pivot rows: read once, not once per k-tile
 
     const int b = blockIdx.z;
     const int tid = threadIdx.x;
@@ -972,6 +973,7 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     const int *map = map_all + (size_t)b * np;
 
     for (int i = tid; i < BM; i += 256) s_map[i] = map[row0 + i];
+    for (int i = tid; i < kdim; i += 256) s_bmap[i] = map[c0 + i];
     __syncthreads();
 
     float16v acc, cin;
@@ -1008,7 +1010,7 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
             const int idx = tid + q * 256;
             if (idx < BK * BN / 4) {
                 const int kk = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
-                const int brow = map[c0 + kt + kk];
+                const int brow = s_bmap[kt + kk];
                 *reinterpret_cast<float4 *>(&s_b[kk * LDB + c4]) =
                     *reinterpret_cast<const float4 *>(src + (size_t)brow * ld + col0 + c4);
             }
