@@ -75,6 +75,9 @@ static constexpr int kMaxW = 32;  // widest sub-panel (columns kept in registers
 static constexpr int kMaxPanelGroups = 4;
 static constexpr int kPanelGroupRows = 4096;
 static constexpr int kXchGranules = 2 * kMaxPanelGroups * 32;  // 8-byte granules per matrix: [parity][group][32]
+// how long a workgroup of a shared panel waits for a partner's record before it gives the matrix up
+// (MI32_RUNTIME_ERROR, output poisoned with NaN): 0.25 s of the 100 MHz s_memrealtime clock
+static constexpr unsigned long long kPanelXchTimeoutTicks = 25000000ull;
 
 // Panel-kernel geometry: NT threads hold the rows at or below the block x w columns in registers, rpt rows
 // each (1024 threads leave <= 128 VGPRs per lane, i.e. rpt * w <= 64 floats of slab).
@@ -110,7 +113,7 @@ BlockedPlan make_blocked_plan(int n, int w, int bw, int batch)
     }
     int rpt = 1;
     while (rpt * nt < p.np) rpt *= 2;
-    if (rpt * 4 > 128 && nt == 512) {  // does not fit with 512 threads: use 1024
+    if (rpt > 8 && nt == 512) {  // no 512-thread instance holds more than 8 rows per lane: use 1024
         nt = 1024;
         rpt = 1;
         while (rpt * nt < p.np) rpt *= 2;
@@ -204,6 +207,12 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
 }
 size_t blocked_workspace_bytes(const BlockedPlan &p, int batch) { return blocked_carve(p, batch, nullptr, nullptr); }
 
+// Shared panels only: true when matrix b was given up (see SubpanelArgs::guard).  Wave-uniform.
+__device__ __forceinline__ bool matrix_given_up(const int *guard, int b)
+{
+    return guard != nullptr && __builtin_amdgcn_readfirstlane(guard[b]) == MI32_RUNTIME_ERROR;
+}
+
 // ---- init: A -> diag(A, I) in the first working copy (makeAugmentedMatrix counterpart,
 //      mat_inv_32.cpp:177-192) + the compact copies of the first two sub-panels' columns ------
 __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restrict__ in, int n, int np, int ld,
@@ -216,6 +225,7 @@ __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restri
     const int i0 = blockIdx.y * 16;
     const float *a = in + (size_t)b * n * n;
     float *m = m0 + (size_t)b * mstride;
+    bool nonfinite = false;  // boundary rule: a NaN / inf anywhere in the input is an invalid matrix
     if (j < np) {
 #pragma unroll 4
         for (int u = 0; u < 16; ++u) {
@@ -224,12 +234,14 @@ __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restri
             float v;
             if (i < n && j < n) v = a[(size_t)i * n + j];
             else v = (i == j) ? 1.0f : 0.0f;
+            nonfinite = nonfinite || (v - v != 0.0f);
             m[(size_t)i * ld + j] = v;
             panel_export_store(ex, tstride, b, np, j, i, v);
         }
     }
     if (blockIdx.y == 0 && j < np) orig[(size_t)b * np + j] = j;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status) status[b] = MI32_OK;
+    // status[b] was zeroed (MI32_OK) by the host before this launch; every writer stores the same value
+    if (nonfinite && status) status[b] = MI32_SINGULAR;
 }
 
 // ---- wave-level arg-max helpers (DPP, no LDS traffic) ----------------------------
@@ -280,6 +292,7 @@ struct __attribute__((aligned(16))) PanelShared {
     float prn_all[W][W];        // the normalised pivot row of every step, exported for the rows above the block
     float bprev[W][W];          // the previous sub-panel's W pivot rows, restricted to this sub-panel's columns
     unsigned gx[2][kMaxPanelGroups][W + 2];  // multi-workgroup panels: every workgroup's winner of this step
+    int lost;                   // multi-workgroup panels: a partner timed out (sticky; zeroed at kernel start)
 };
 
 // which matrix row register row k of thread tid holds: V consecutive rows per thread so that the
@@ -414,17 +427,26 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
         if (wave_u < pg.ngroups) {  // wave g collects workgroup g's record (its own workgroup's too)
             const unsigned long long *src = xq + wave_u * 32;
             unsigned long long v = 0ull;
-            int spins = 0;
+            // Every spin is bounded in TIME (s_memrealtime: 100 MHz).  A partner that has not shown up after
+            // kPanelXchTimeoutTicks is given up for good: its record counts as "no candidate" (key 0) in this and
+            // every later step -- all labels stay valid positions of the present rows -- the matrix is flagged
+            // MI32_RUNTIME_ERROR, skipped by every later launch of the call and handed out NaN-filled.
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
             for (;;) {
                 if (lane < W + 2) v = __hip_atomic_load(&src[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool ok = (lane >= W + 2) || ((unsigned)(v >> 32) == tag);
                 if (__all(ok)) break;
-                if (++spins > (1 << 22)) { pg.timed_out = true; break; }
+                if (pg.timed_out || __builtin_amdgcn_s_memrealtime() - t_start > kPanelXchTimeoutTicks) {
+                    v = 0ull;
+                    if (lane == 0) sh.lost = 1;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
             if (lane < W + 2) sh.gx[par][wave_u][lane] = (unsigned)v;
         }
         __syncthreads();
+        if (sh.lost != 0) pg.timed_out = true;  // workgroup-uniform from here on
         int gw = 0;
         key = ((unsigned long long)sh.gx[par][0][W + 1] << 32) | sh.gx[par][0][W];
 #pragma unroll
@@ -473,7 +495,7 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
     if (my_group_won && wave_u == wv) {
         // this wave's scratch slot still holds the winning row as found: its pivot entry decides "singular"
         const float cpiv = sh.cand[wave_u][R];
-        if (cpiv == 0.0f || cpiv != cpiv) singular = true;
+        if (cpiv == 0.0f || cpiv - cpiv != 0.0f) singular = true;  // zero, NaN or infinite pivot
         if (!MULTI && lane < W) sh.prn_all[R][lane] = sh.prn[par][wv][lane];
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
@@ -515,6 +537,9 @@ struct SubpanelArgs {
     int *rowsrc, *orig;
     float *aux_out;          // [2][kMaxW*kMaxW] per matrix: normalised pivot rows of s; pivot rows of s-1 x columns of s
     int *status;
+    const int *guard;        // non-null for plans with shared panels: status words; a matrix flagged
+                             // MI32_RUNTIME_ERROR (a panel lost a partner: its row maps are not to be trusted)
+                             // is skipped by every later launch and comes out as NaN
     int ngroups;             // workgroups per panel (> 1: MULTI instances, kPanelGroupRows rows each)
     unsigned long long *xch; // [batch][kXchGranules] exchange granules of the multi-workgroup panels
     unsigned tag_base;       // unique per panel launch within a call
@@ -548,6 +573,7 @@ template <int NT, int RPT, int W, bool FUSED, bool MULTI>
 __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp, unsigned char *smem)
 {
     static_assert(!(FUSED && MULTI), "multi-workgroup panels are never fused");
+    if (matrix_given_up(A.guard, b)) return;
     const bool has_prev = FUSED && A.has_prev;
     constexpr int V = RPT < 4 ? RPT : 4;
     constexpr int NW = NT / 64;
@@ -563,6 +589,7 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     const float *pt = A.pt_in + (size_t)b * A.tstride;
     const int *invsub_prev = A.invsub_prev + (size_t)b * np;
     if (tid < W) sh.key[tid] = 0ull;
+    if (tid == 0) sh.lost = 0;
 
     // -- the slab and every row's label at entry (its position after the previous sub-panel's swaps)
     float a[RPT][W];
@@ -721,8 +748,9 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
         }
     }
     // only the wave that won a step has looked at that step's pivot: any wave may raise the flag
-    if (singular && lane == 0 && A.status) A.status[b] = MI32_SINGULAR;
-    if (pg.timed_out && lane == 0 && A.status) A.status[b] = MI32_RUNTIME_ERROR;  // a partner workgroup never showed up
+    // (atomicMax: a later "singular" must not hide "a partner workgroup never showed up")
+    if (singular && lane == 0 && A.status) atomicMax(&A.status[b], (int)MI32_SINGULAR);
+    if (pg.timed_out && lane == 0 && A.status) atomicMax(&A.status[b], (int)MI32_RUNTIME_ERROR);
 }
 
 // One pivot step of a row that is not a candidate, for the in-block update tiles: the row's BK panel entries
@@ -780,6 +808,7 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
     const int tiles_x = A.kb / 64;
     const int wgs_per_matrix = tiles_x * (np / 64) / NG;
     const int b = u / wgs_per_matrix;
+    if (matrix_given_up(A.guard, b)) return;
     const int id = (u % wgs_per_matrix) * NG + grp;
     const int tx = id % tiles_x, ty = id / tiles_x;
     const int lane = tid & 63;
@@ -949,7 +978,8 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
                                                               const float *__restrict__ g_all, size_t gstride,
                                                               int np, int ld, size_t mstride, int c0, int kdim,
                                                               int col_lo, const int *__restrict__ map_all,
-                                                              PanelExport ex, size_t tstride)
+                                                              PanelExport ex, size_t tstride,
+                                                              const int *__restrict__ guard)
 {
     constexpr int BM = 64, BN = 64;
     constexpr int PADA = (32 / BK) > 0 ? (32 / BK) : 1;
@@ -961,6 +991,7 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     __shared__ int s_bmap[kMaxBW];  // the block's pivot rows: read once, not once per k-tile
 
     const int b = blockIdx.z;
+    if (matrix_given_up(guard, b)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -1041,9 +1072,11 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
 }
 
 // ---- getInvertedMatrix counterpart: undo the column permutation ----------------
-__global__ void invert_perm_ld_kernel(const int *__restrict__ orig, int *__restrict__ invp, int n, int istride)
+__global__ void invert_perm_ld_kernel(const int *__restrict__ orig, int *__restrict__ invp, int n, int istride,
+                                      const int *__restrict__ guard)
 {
     const int b = blockIdx.y;
+    if (matrix_given_up(guard, b)) return;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < n) invp[(size_t)b * istride + orig[(size_t)b * istride + c]] = c;
 }
@@ -1053,7 +1086,8 @@ __global__ void invert_perm_ld_kernel(const int *__restrict__ orig, int *__restr
 __global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *__restrict__ w_all, int ld, int np,
                                                                     size_t wstride, const int *__restrict__ invp,
                                                                     int istride, int n, int rows_per_block,
-                                                                    float *__restrict__ out)
+                                                                    float *__restrict__ out,
+                                                                    const int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) float s_rows[];  // [rows_per_block][np]
     const int b = blockIdx.y;
@@ -1062,6 +1096,12 @@ __global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *
     float *o = out + (size_t)b * n * n;
     const int i0 = blockIdx.x * rows_per_block;
     const int nr = (n - i0 < rows_per_block) ? (n - i0) : rows_per_block;
+    // a matrix whose shared panel lost a partner workgroup went on with stale data: hand out NaN, not numbers
+    if (status != nullptr && __builtin_amdgcn_readfirstlane(status[b]) == MI32_RUNTIME_ERROR) {
+        for (int r = 0; r < nr; ++r)
+            for (int j = tid; j < n; j += 256) o[(size_t)(i0 + r) * n + j] = __builtin_nanf("");
+        return;
+    }
     for (int r = 0; r < nr; ++r)
         for (int c4 = tid * 4; c4 < np; c4 += 1024)
             *reinterpret_cast<float4 *>(&s_rows[(size_t)r * np + c4]) =
@@ -1113,7 +1153,12 @@ static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelA
     if (A.ngroups > 1) {  // multi-workgroup panel: never fused, W = 16 (what the plan gives every block then)
         if (A.upd_on || w != 16) return hipErrorInvalidValue;
         constexpr size_t lds = subpanel_lds_bytes<1024, 4, 16, false>();
-        hipLaunchKernelGGL((gj_panel_multi_kernel<16>), dim3(A.batch * A.ngroups), dim3(1024), lds, stream, A);
+        // MI32_DEBUG_DROP_PANEL_GROUP=1 (tests only, host side only): the last workgroup of the grid is never
+        // launched, i.e. one panel loses a partner -- what a foreign kernel holding the CUs would cause
+        const char *dv = std::getenv("MI32_DEBUG_DROP_PANEL_GROUP");
+        const int drop = dv ? std::atoi(dv) : 0;
+        hipLaunchKernelGGL((gj_panel_multi_kernel<16>), dim3(A.batch * A.ngroups - (drop ? 1 : 0)), dim3(1024), lds,
+                           stream, A);
         return hipSuccess;
     }
     const bool fused = A.upd_on != 0;
@@ -1168,6 +1213,9 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     int fused_rows = 2048;  // see "Fused mode" below; fused instances exist for at most 2048 rows
     if (const char *ev = std::getenv("MI32_FUSED_ROWS")) fused_rows = std::atoi(ev) < 2048 ? std::atoi(ev) : 2048;
     const PanelExport no_export = {ws.pt[0], ws.pt_bstride, -(1 << 30), 1, 0};
+    if (d_status) {  // MI32_OK; the init kernel flags non-finite input, the panels bad pivots and lost partners
+        if ((e = hipMemsetAsync(d_status, 0, sizeof(int) * (size_t)batch, stream)) != hipSuccess) return e;
+    }
     {
         // the first two sub-panels of the first block are exported as they are: the first has no pending
         // update at all, the second gets the first one's update in its panel's prologue
@@ -1197,6 +1245,8 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
             attr_set = true;
         }
     }
+    // plans with shared panels: every launch skips a matrix whose panel lost a partner (SubpanelArgs::guard)
+    const int *guard = p.multi_panel ? d_status : nullptr;
     unsigned panel_launches = 0;  // tags of the multi-workgroup panels' exchange granules: unique per launch
     if (p.multi_panel) {  // no stale tag of an earlier call may match
         if ((e = hipMemsetAsync(ws.xch, 0, (size_t)kXchGranules * sizeof(unsigned long long) * batch, stream)) != hipSuccess)
@@ -1222,6 +1272,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
             P.np = np; P.n = p.n; P.ld = p.ld; P.batch = batch;
             P.mstride = ws.mstride; P.tstride = ws.tstride;
             P.u_exp = no_export;
+            P.guard = guard;
             SubpanelArgs U = P;    // the update half
             if (s < S) {
                 P.panel_on = 1;
@@ -1307,7 +1358,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                     // small tiles: only kb_next columns, so 64x64 gives 4x the workgroups of 128x128
                     hipLaunchKernelGGL((gj_rank_update_kernel<32>), dim3(kb_next / 64, np / 64, batch), dim3(256), 0,
                                        stream, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, next, rowsrc, exn,
-                                       ws.tstride);
+                                       ws.tstride, guard);
                 }
                 // (B): everything else, on the second stream, after this block's panel phase
                 ev = (ev + 1) % (ex.n_events / 2);
@@ -1326,7 +1377,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                     hipLaunchKernelGGL((gj_rank_bw2_persistent_kernel<MI32_BW_BK>), dim3(ex.aux_workgroups, batch),
                                        dim3(256), lds_persistent, ex.aux, cur, oth, x, ws.mstride, ws.gk, ws.gkstride, np,
                                        p.ld, ws.mstride, C0, kb, rowsrc, copy, no_export, ws.tstride, next,
-                                       next + kb_next);
+                                       next + kb_next, guard);
                 }
                 if ((e = hipEventRecord(ex.events[ev], ex.aux)) != hipSuccess) return e;
                 pending_b = true;
@@ -1334,7 +1385,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 ProfScope ps(prof, KC_UPDATE_OUT, stream);
                 hipLaunchKernelGGL((gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS>), dim3((np / 128) * (np / 128), batch),
                                    dim3(256), rank_bw2_lds_bytes<MI32_BW_BK>(kb), stream, cur, oth, x, ws.mstride, ws.gk,
-                                   ws.gkstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, exn, ws.tstride, 0, 0);
+                                   ws.gkstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, exn, ws.tstride, 0, 0, guard);
             }
             float *t = cur; cur = oth; oth = t;
         } else {
@@ -1347,14 +1398,14 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     ProfScope ps(prof, KC_FINISH, stream);
     // over ALL np entries: orig is a permutation of [0, np), so every invp[j] is defined and in range
     hipLaunchKernelGGL(invert_perm_ld_kernel, dim3((np + 255) / 256, batch), dim3(256), 0, stream, ws.orig, ws.invp,
-                       np, np);
+                       np, np, guard);
     {
         int rpb = (64 * 1024) / (np * (int)sizeof(float));  // rows per workgroup: at most 64 KiB of LDS
         if (rpb < 1) rpb = 1;
         if (rpb > 8) rpb = 8;
         hipLaunchKernelGGL(unpermute_columns_ld_kernel, dim3((p.n + rpb - 1) / rpb, batch), dim3(256),
                            (size_t)rpb * np * sizeof(float), stream, cur, p.ld, np, ws.mstride, ws.invp, np, p.n, rpb,
-                           d_inv);
+                           d_inv, d_status);
     }
     return hipGetLastError();
 }

@@ -35,9 +35,18 @@ struct EventProfiler : public Profiler {
         (void)hipEventCreate(&e);
         return e;
     }
-    void begin(int, hipStream_t s) override { cur = get(); (void)hipEventRecord(cur, s); }
+    // Records accumulate until mi32_get_profile() collects them: a caller that leaves profiling on and never
+    // collects stops recording after kMaxRecs launches instead of growing without bound.
+    static constexpr size_t kMaxRecs = 1u << 20;
+    void begin(int, hipStream_t s) override
+    {
+        if (recs.size() >= kMaxRecs) { cur = nullptr; return; }
+        cur = get();
+        (void)hipEventRecord(cur, s);
+    }
     void end(int k, hipStream_t s) override
     {
+        if (!cur) return;
         hipEvent_t b = get();
         (void)hipEventRecord(b, s);
         recs.push_back({k, cur, b});
@@ -83,11 +92,18 @@ struct mi32_context {
     float *d_in = nullptr, *d_out = nullptr;
     int *d_status = nullptr;
     size_t io_floats = 0, status_ints = 0;  // io_floats: capacity of d_in / d_out in 4-byte units
+    // status words of device-resident calls that pass no status buffer: the kernels always have one to flag
+    // a bad pivot or a lost panel partner in (a given-up matrix is then skipped and comes out as NaN)
+    int *d_istatus = nullptr;
+    size_t istatus_ints = 0;
     std::mutex mu;
 };
 
 static thread_local std::string g_last_error;
-static double g_last_total = 0.0, g_last_compute = 0.0;
+// Host-pointer entry points (fp32 and fp64 alike) share the default context's staging buffers and the two
+// timing words below: ONE mutex serialises them all.
+static std::mutex g_host_call_mu;
+static double g_last_total = 0.0, g_last_compute = 0.0;  // guarded by g_host_call_mu
 
 static int fail(hipError_t e, const char *what)
 {
@@ -146,13 +162,40 @@ static size_t ws_bytes_for(const mi32_context *h, int n, int batch, int algo)
     return a > r ? a : r;
 }
 
+static int sync_all_streams(mi32_context *h)
+{
+    MI32_HIP(hipStreamSynchronize(h->stream));
+    if (h->aux_stream) MI32_HIP(hipStreamSynchronize(h->aux_stream));
+    if (h->split_stream) MI32_HIP(hipStreamSynchronize(h->split_stream));
+    return MI32_OK;
+}
+
+// the status buffer a device-resident call runs with: the caller's, or the context's own
+static int status_buffer(mi32_context *h, int *d_status, int batch, int **out)
+{
+    *out = d_status;
+    if (d_status) return MI32_OK;
+    if ((size_t)batch > h->istatus_ints) {
+        if (h->d_istatus) {
+            int rc = sync_all_streams(h);
+            if (rc != MI32_OK) return rc;
+            MI32_HIP(hipFree(h->d_istatus));
+            h->d_istatus = nullptr;
+            h->istatus_ints = 0;
+        }
+        MI32_HIP(hipMalloc((void **)&h->d_istatus, (size_t)batch * sizeof(int)));
+        h->istatus_ints = (size_t)batch;
+    }
+    *out = h->d_istatus;
+    return MI32_OK;
+}
+
 static int ensure_ws(mi32_context *h, size_t bytes)
 {
     if (bytes <= h->ws_bytes) return MI32_OK;
     if (h->ws) {
-        MI32_HIP(hipStreamSynchronize(h->stream));
-        if (h->aux_stream) MI32_HIP(hipStreamSynchronize(h->aux_stream));
-        if (h->split_stream) MI32_HIP(hipStreamSynchronize(h->split_stream));
+        int rc = sync_all_streams(h);
+        if (rc != MI32_OK) return rc;
         MI32_HIP(hipFree(h->ws));
         h->ws = nullptr;
         h->ws_bytes = 0;
@@ -220,6 +263,7 @@ int mi32_destroy(mi32_handle_t h)
     if (h->d_in) (void)hipFree(h->d_in);
     if (h->d_out) (void)hipFree(h->d_out);
     if (h->d_status) (void)hipFree(h->d_status);
+    if (h->d_istatus) (void)hipFree(h->d_istatus);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->switch_event) (void)hipEventDestroy(h->switch_event);
     if (h->aux_stream) {
@@ -338,6 +382,8 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
     const int algo = resolve_algo(h, n);
     int rc = ensure_ws(h, ws_bytes_for(h, n, batch, algo));
     if (rc != MI32_OK) return rc;
+    rc = status_buffer(h, d_status, batch, &d_status);
+    if (rc != MI32_OK) return rc;
     hipError_t e;
     if (algo == MI32_ALGO_SWEEP)
         e = sweep_invert(make_sweep_plan(n), d_a, d_inv, batch, d_status, h->ws, h->stream, h->prof);
@@ -366,7 +412,7 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
             e = blocked_invert(p, d_a, d_inv, b0, d_status, h->ws, ex0);
             if (e == hipSuccess)
                 e = blocked_invert(p, d_a + (size_t)b0 * mat, d_inv + (size_t)b0 * mat, b1,
-                                   d_status ? d_status + b0 : nullptr, ws1, ex1);
+                                   d_status + b0, ws1, ex1);
             MI32_HIP(hipEventRecord(h->la_events[1], h->split_stream));
             MI32_HIP(hipStreamWaitEvent(h->stream, h->la_events[1], 0));
         }
@@ -382,6 +428,8 @@ int mi32_inv_device_f64(mi32_handle_t h, const double *d_a, int n, int batch, do
     MI32_HIP(hipSetDevice(h->device));
     const SweepPlan p = make_sweep_plan(n);
     int rc = ensure_ws(h, sweep_workspace_bytes(p, batch, sizeof(double)));
+    if (rc != MI32_OK) return rc;
+    rc = status_buffer(h, d_status, batch, &d_status);
     if (rc != MI32_OK) return rc;
     hipError_t e = sweep_invert_f64(p, d_a, d_inv, batch, d_status, h->ws, h->stream, h->prof);
     if (e != hipSuccess) return fail(e, "kernel launch");
@@ -469,8 +517,7 @@ int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int
     mi32_context *h = nullptr;
     int rc = default_context(&h);
     if (rc != MI32_OK) return rc;
-    static std::mutex call_mu;  // one host-pointer call at a time: the staging buffers are shared
-    std::lock_guard<std::mutex> lk(call_mu);
+    std::lock_guard<std::mutex> lk(g_host_call_mu);  // one host-pointer call at a time: the staging buffers are shared
     const auto t0 = std::chrono::steady_clock::now();
     MI32_HIP(hipSetDevice(h->device));
     const size_t floats = (size_t)batch * n * n;
@@ -495,6 +542,9 @@ int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int
         if (status) status[b] = st[(size_t)b];
         if (st[(size_t)b] > worst) worst = st[(size_t)b];
     }
+    if (worst == MI32_RUNTIME_ERROR)  // the only status-borne runtime error (mi32_blocked.hip, shared panels)
+        g_last_error = "a workgroup of a shared panel timed out waiting for its partners (the device was not ours "
+                       "alone); the affected inverse is NaN-filled -- retry, or set MI32_MULTI_PANEL=0";
     if (env_int("MI32_VERBOSE", 0)) {
         // the reference's two stdout lines (mat_inv_32.cpp:385-386)
         std::printf("Tempo Totale Impiegato: %g seconds\nTempo Computazione: %g seconds\n", g_last_total,
@@ -521,8 +571,7 @@ int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *in
     mi32_context *h = nullptr;
     int rc = default_context(&h);
     if (rc != MI32_OK) return rc;
-    static std::mutex call_mu;  // the staging buffers are shared with the fp32 host-pointer calls
-    std::lock_guard<std::mutex> lk(call_mu);
+    std::lock_guard<std::mutex> lk(g_host_call_mu);  // the staging buffers are shared with the fp32 host-pointer calls
     const auto t0 = std::chrono::steady_clock::now();
     MI32_HIP(hipSetDevice(h->device));
     const size_t elems = (size_t)n * n;
@@ -548,6 +597,7 @@ int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *in
 
 int mi32_last_timing(double *total_seconds, double *compute_seconds)
 {
+    std::lock_guard<std::mutex> lk(g_host_call_mu);
     if (total_seconds) *total_seconds = g_last_total;
     if (compute_seconds) *compute_seconds = g_last_compute;
     return MI32_OK;

@@ -281,9 +281,11 @@ template <int BK, int WPS, int BN = 128>
 __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
     const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
-    const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo, int skip_hi)
+    const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo, int skip_hi,
+    const int *__restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) float rb_smem[];
+    if (guard != nullptr && __builtin_amdgcn_readfirstlane(guard[blockIdx.y]) == MI32_RUNTIME_ERROR) return;  // given up
     int rt, ct;
     rb_tile_of(blockIdx.x, np / 128, np / BN, rt, ct);
     rank_bw2_tile<BK, BN>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
@@ -299,9 +301,11 @@ template <int BK>
 __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
     const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
-    const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo, int skip_hi)
+    const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo, int skip_hi,
+    const int *__restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) float rb_smem[];
+    if (guard != nullptr && __builtin_amdgcn_readfirstlane(guard[blockIdx.y]) == MI32_RUNTIME_ERROR) return;  // given up
     const int T = np / 128;
     for (int id = blockIdx.x; id < T * T; id += gridDim.x) {
         int rt, ct;

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_init_kernel(const T *__re
     const T *a = in + (size_t)b * n * n;
     T *w = w0 + (size_t)b * wstride;
     PivotRec<T> best = PivotRec<T>::none();
+    bool nonfinite = false;  // boundary rule: a NaN / inf anywhere in the input is an invalid matrix
     if (j4 < ld) {
 #pragma unroll 4
         for (int u = 0; u < TR; ++u) {
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_init_kernel(const T *__re
             v.y = (j4 + 1 < n) ? a[(size_t)i * n + j4 + 1] : T(0);
             v.z = (j4 + 2 < n) ? a[(size_t)i * n + j4 + 2] : T(0);
             v.w = (j4 + 3 < n) ? a[(size_t)i * n + j4 + 3] : T(0);
+            nonfinite = nonfinite || (v.x - v.x != T(0)) || (v.y - v.y != T(0)) || (v.z - v.z != T(0)) || (v.w - v.w != T(0));
             *reinterpret_cast<Vec4<T> *>(w + (size_t)i * ld + j4) = v;
             if (j4 == 0) {
                 const PivotRec<T> k = PivotRec<T>::make(v.x, i);
@@ -177,8 +179,9 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_init_kernel(const T *__re
         if (tid == 0) keys[(size_t)b * npart + blockIdx.y] = best;
         for (int u = tid; u < TR; u += kSweepThreads)
             if (row0 + u < n) orig[(size_t)b * n + row0 + u] = row0 + u;
-        if (blockIdx.y == 0 && tid == 0 && status) status[b] = MI32_OK;
     }
+    // status[b] was zeroed (MI32_OK) by the host before this launch; every writer stores the same value
+    if (nonfinite && status) status[b] = MI32_SINGULAR;
 }
 
 // ---- one pivot step ---------------------------------------------------------
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(kSweepThreads) void gj_sweep_step_kernel(const T *_
             og[r] = og[p];
             og[p] = t;
         }
-        if (status && (piv == T(0) || piv != piv)) status[b] = MI32_SINGULAR;
+        if (status && (piv == T(0) || piv - piv != T(0))) status[b] = MI32_SINGULAR;  // zero, NaN or infinite pivot
     }
 }
 
@@ -339,6 +342,10 @@ static hipError_t sweep_run(const SweepPlan &p, const T *d_a, T *d_inv, int batc
     const dim3 block(kSweepThreads);
     T *w0 = (T *)ws.w0, *w1 = (T *)ws.w1;
     PivotRec<T> *k0 = (PivotRec<T> *)ws.k0, *k1 = (PivotRec<T> *)ws.k1;
+    if (d_status) {
+        hipError_t e = hipMemsetAsync(d_status, 0, sizeof(int) * (size_t)batch, stream);  // MI32_OK
+        if (e != hipSuccess) return e;
+    }
     {
         ProfScope ps(prof, KC_INIT, stream);
         hipLaunchKernelGGL((sweep_init_kernel<T, TR>), grid, block, 0, stream, d_a, p.n, p.ld, ws.wstride, w0, k0,

@@ -28,8 +28,10 @@ extern "C" {
 typedef enum mi32_status {
     MI32_OK = 0,
     MI32_BAD_SHAPE = 1,     /* reference: returns {} (mat_inv_32.cpp:206-215)                 */
-    MI32_SINGULAR = 2,      /* a zero/NaN pivot was met (reference: inf/NaN out, unchecked)  */
-    MI32_RUNTIME_ERROR = 3  /* HIP error (reference: unreachable catch, mat_inv_32.cpp:391)  */
+    MI32_SINGULAR = 2,      /* invalid matrix: a zero / NaN / infinite pivot was met, or the input holds a
+                             * non-finite entry (reference: inf/NaN out, unchecked; README.md:54 "empty vector") */
+    MI32_RUNTIME_ERROR = 3  /* HIP error (reference: unreachable catch, mat_inv_32.cpp:391); as a per-matrix
+                             * status: a shared panel lost a partner workgroup, that inverse is NaN-filled */
 } mi32_status;
 
 typedef enum mi32_algo {
@@ -80,7 +82,7 @@ int mi32_reserve(mi32_handle_t h, int n, int batch);
 /* ---- device-resident entry points ---------------------------------------- */
 /* d_a, d_inv: device pointers, batch x n x n fp32 row-major, contiguous; d_a is
  * not modified, d_inv may not alias d_a.  d_status: device int[batch] (may be
- * NULL).  Asynchronous: everything is enqueued on the context's stream and the
+ * NULL: the context then keeps the status words itself).  Asynchronous: everything is enqueued on the context's stream and the
  * call returns without synchronising.  The call shape, minus the host copies,
  * of mat_inv_32.cpp:292-376 (makeAugmented -> N pivot steps -> getInverted). */
 int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *d_inv, int *d_status);

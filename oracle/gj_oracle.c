@@ -16,6 +16,12 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#endif
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ---- helpers ---------------------------------------------------------- */
 
@@ -26,6 +32,24 @@ static inline float cand_abs(float x)
 {
     float v = fabsf(x);
     return (v == v) ? v : -1.0f;
+}
+
+/* Boundary rule (README.md:54 "in case of invalid matrix an empty vector is returned"; the experiment twin's
+ * exact-identity check, matrix_inversion_FP32.cpp:814-835, rejects every result that went through a zero or
+ * non-finite pivot): status GJO_SINGULAR when a pivot is zero, NaN or infinite, or when the INPUT holds a
+ * non-finite entry (a NaN never wins the search, R:90,123, but it poisons the result). */
+static inline int bad_pivot(double piv) { return piv == 0.0 || piv != piv || piv - piv != 0.0; }
+static int input_status_f32(const float *in, int n)
+{
+    for (size_t i = 0; i < (size_t)n * n; ++i)
+        if (in[i] - in[i] != 0.0f) return GJO_SINGULAR; /* NaN or +-inf */
+    return GJO_OK;
+}
+static int input_status_f64(const double *in, int n)
+{
+    for (size_t i = 0; i < (size_t)n * n; ++i)
+        if (in[i] - in[i] != 0.0) return GJO_SINGULAR;
+    return GJO_OK;
 }
 
 static inline float elim(float cij, float cir, float crj, int arith_mode)
@@ -168,7 +192,7 @@ int gjo_matrix_inv_32(const float *in, size_t in_len, int n, float *out, int piv
         free(buf1);
         return GJO_BAD_SHAPE;
     }
-    int status = GJO_OK;
+    int status = input_status_f32(in, n);
     make_augmented(buf0, in, n); /* R:292-297 */
 
     for (int r = 0; r < n; ++r) { /* R:317 */
@@ -185,7 +209,7 @@ int gjo_matrix_inv_32(const float *in, size_t in_len, int n, float *out, int piv
             piv = src[(size_t)p * w + r];
         }
         if (pivots) pivots[r] = p;
-        if (piv == 0.0f || piv != piv) status = GJO_SINGULAR;
+        if (bad_pivot((double)piv)) status = GJO_SINGULAR;
 
         /* pivotElementsKernel, R:154-173: swap rows r <-> p over all 2N columns */
         if (p != r) {
@@ -242,13 +266,13 @@ int gjo_matrix_inv_32_inplace(const float *in, size_t in_len, int n, float *out,
     }
     memcpy(m, in, sizeof(float) * ld * n);
     for (int i = 0; i < n; ++i) orig[i] = i;
-    int status = GJO_OK;
+    int status = input_status_f32(in, n);
 
     for (int r = 0; r < n; ++r) {
         const int p = max_pivot_true(m, ld, n, r);
         const float piv = m[(size_t)p * ld + r];
         if (pivots) pivots[r] = p;
-        if (piv == 0.0f || piv != piv) status = GJO_SINGULAR;
+        if (bad_pivot((double)piv)) status = GJO_SINGULAR;
         if (p != r) {
             for (int j = 0; j < n; ++j) {
                 float t = m[(size_t)r * ld + j];
@@ -299,7 +323,7 @@ int gjo_matrix_inv_64_inplace(const double *in, size_t in_len, int n, double *ou
     }
     memcpy(m, in, sizeof(double) * ld * n);
     for (int i = 0; i < n; ++i) orig[i] = i;
-    int status = GJO_OK;
+    int status = input_status_f64(in, n);
     for (int r = 0; r < n; ++r) {
         int p = r;
         double best = -1.0;
@@ -309,7 +333,7 @@ int gjo_matrix_inv_64_inplace(const double *in, size_t in_len, int n, double *ou
         }
         const double piv = m[(size_t)p * ld + r];
         if (pivots) pivots[r] = p;
-        if (piv == 0.0 || piv != piv) status = GJO_SINGULAR;
+        if (bad_pivot((double)piv)) status = GJO_SINGULAR;
         if (p != r) {
             for (int j = 0; j < n; ++j) {
                 double t = m[(size_t)r * ld + j];
@@ -360,7 +384,7 @@ int gjo_matrix_inv_32_blocked(const float *in, size_t in_len, int n, float *out,
     }
     memcpy(m, in, sizeof(float) * ld * n);
     for (int i = 0; i < n; ++i) orig[i] = i;
-    int status = GJO_OK;
+    int status = input_status_f32(in, n);
 
     for (int c0 = 0; c0 < n; c0 += w) {
         const int kw = (c0 + w <= n) ? w : n - c0;
@@ -370,7 +394,7 @@ int gjo_matrix_inv_32_blocked(const float *in, size_t in_len, int n, float *out,
             const int p = max_pivot_true(m, ld, n, r);
             const float piv = m[(size_t)p * ld + r];
             if (pivots) pivots[r] = p;
-            if (piv == 0.0f || piv != piv) status = GJO_SINGULAR;
+            if (bad_pivot((double)piv)) status = GJO_SINGULAR;
             if (p != r) { /* swap across ALL columns right away */
                 for (int j = 0; j < n; ++j) {
                     float t = m[(size_t)r * ld + j];
@@ -423,22 +447,76 @@ int gjo_matrix_inv_32_blocked(const float *in, size_t in_len, int n, float *out,
 /* add_last = 0: the fmaf chain starts from the old value (in-block updates);
  * add_last = 1: the chain starts from zero and the old value is added at the end (rank-bw updates:
  *               mi32_blocked.hip keeps only the accumulators live across its k-loop that way). */
+/* One row of a rank-kw update over the columns [ja, jb) (none of them in the block).  Every output element
+ * is its own k-ascending fmaf chain, so the order in which elements are visited -- 64 at a time with AVX2
+ * FMA lanes here, one at a time in the scalar tail and in the portable build -- does not change a bit
+ * (tests/test_oracle.py compares the two builds). */
+static void rank_update_row(float *mi, const float *g, const float *rs, size_t n, int kw, int ja, int jb,
+                            int in_block, int add_last)
+{
+    int j = ja;
+#if defined(__AVX2__) && defined(__FMA__)
+    for (; j + 64 <= jb; j += 64) {
+        __m256 old[8], acc[8];
+        for (int v = 0; v < 8; ++v) {
+            old[v] = in_block ? _mm256_setzero_ps() : _mm256_loadu_ps(mi + j + 8 * v);
+            acc[v] = add_last ? _mm256_setzero_ps() : old[v];
+        }
+        for (int k = 0; k < kw; ++k) {
+            const __m256 b = _mm256_set1_ps(g[k]);
+            const float *r = rs + (size_t)k * n + j;
+            for (int v = 0; v < 8; ++v) acc[v] = _mm256_fmadd_ps(b, _mm256_loadu_ps(r + 8 * v), acc[v]);
+        }
+        for (int v = 0; v < 8; ++v)
+            _mm256_storeu_ps(mi + j + 8 * v, add_last ? _mm256_add_ps(acc[v], old[v]) : acc[v]);
+    }
+    for (; j + 8 <= jb; j += 8) {
+        const __m256 old = in_block ? _mm256_setzero_ps() : _mm256_loadu_ps(mi + j);
+        __m256 acc = add_last ? _mm256_setzero_ps() : old;
+        for (int k = 0; k < kw; ++k)
+            acc = _mm256_fmadd_ps(_mm256_set1_ps(g[k]), _mm256_loadu_ps(rs + (size_t)k * n + j), acc);
+        _mm256_storeu_ps(mi + j, add_last ? _mm256_add_ps(acc, old) : acc);
+    }
+#endif
+    for (; j < jb; ++j) {
+        const float old = in_block ? 0.0f : mi[j];
+        float acc = add_last ? 0.0f : old;
+        for (int k = 0; k < kw; ++k) acc = fmaf(g[k], rs[(size_t)k * n + j], acc);
+        mi[j] = add_last ? acc + old : acc;
+    }
+}
+
+static int __attribute__((unused)) oracle_threads(void)
+{
+#ifdef _OPENMP
+    const char *e = getenv("GJO_THREADS");
+    int t = e ? atoi(e) : 0;
+    if (t <= 0) {
+        t = omp_get_num_procs();
+        if (t > 16) t = 16; /* a GPU box hands a 1-GPU job 16 CPUs of a 256-CPU host */
+    }
+    return t;
+#else
+    return 1;
+#endif
+}
+
 static void rank_update(float *m, size_t ld, int n, int r0, int kw, int j_lo, int j_hi, float *rs, int add_last)
 {
     /* rs: kw x n snapshot of rows [r0, r0+kw) */
     for (int k = 0; k < kw; ++k) memcpy(rs + (size_t)k * n, m + (size_t)(r0 + k) * ld, sizeof(float) * n);
+    const int a_hi = (r0 < j_hi) ? r0 : j_hi;           /* columns left of the block:  [j_lo, a_hi) */
+    const int b_lo = (r0 + kw > j_lo) ? r0 + kw : j_lo; /* columns right of the block: [b_lo, j_hi) */
+    /* rows are independent (each reads the snapshot and its own G entries, writes its own columns) */
+#ifdef _OPENMP
+    const int nthreads = ((double)n * kw * (j_hi - j_lo) > 4e7) ? oracle_threads() : 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
     for (int i = 0; i < n; ++i) {
         float *mi = m + (size_t)i * ld;
-        const float *g = mi + r0;
         const int in_block = (i >= r0 && i < r0 + kw);
-        for (int j = j_lo; j < j_hi; ++j) {
-            if (j >= r0 && j < r0 + kw) continue;
-            const float old = in_block ? 0.0f : mi[j];
-            const int last = add_last;
-            float acc = last ? 0.0f : old;
-            for (int k = 0; k < kw; ++k) acc = fmaf(g[k], rs[(size_t)k * n + j], acc);
-            mi[j] = last ? acc + old : acc;
-        }
+        if (j_lo < a_hi) rank_update_row(mi, mi + r0, rs, (size_t)n, kw, j_lo, a_hi, in_block, add_last);
+        if (b_lo < j_hi) rank_update_row(mi, mi + r0, rs, (size_t)n, kw, b_lo, j_hi, in_block, add_last);
     }
 }
 
@@ -458,7 +536,7 @@ int gjo_matrix_inv_32_blocked2w(const float *in, size_t in_len, int n, float *ou
     }
     memcpy(m, in, sizeof(float) * ld * n);
     for (int i = 0; i < n; ++i) orig[i] = i;
-    int status = GJO_OK;
+    int status = input_status_f32(in, n);
 
     int blk = 0;
     for (int C0 = 0; C0 < n; C0 += bw, ++blk) {
@@ -473,7 +551,7 @@ int gjo_matrix_inv_32_blocked2w(const float *in, size_t in_len, int n, float *ou
                 const int p = max_pivot_true(m, ld, n, r);
                 const float piv = m[(size_t)p * ld + r];
                 if (pivots) pivots[r] = p;
-                if (piv == 0.0f || piv != piv) status = GJO_SINGULAR;
+                if (bad_pivot((double)piv)) status = GJO_SINGULAR;
                 if (p != r) {
                     for (int j = 0; j < n; ++j) {
                         float t = m[(size_t)r * ld + j];

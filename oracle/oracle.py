@@ -28,10 +28,16 @@ _lib = None
 
 def build(force: bool = False) -> None:
     """Compile the C restatement (gcc, seconds)."""
-    fast = os.path.join(_HERE, "libgj_oracle.so")
-    gen = os.path.join(_HERE, "libgj_oracle_generic.so")
-    if force or not (os.path.exists(fast) and os.path.exists(gen)):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    # make decides what is stale (a gj_oracle.c newer than the .so rebuilds it); where the sources travel
+    # without a toolchain the prebuilt libraries are used as they are
+    cmd = ["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + ["all"]
+    try:
+        subprocess.check_call(cmd)
+    except (OSError, subprocess.CalledProcessError):
+        fast = os.path.join(_HERE, "libgj_oracle.so")
+        gen = os.path.join(_HERE, "libgj_oracle_generic.so")
+        if not (os.path.exists(fast) and os.path.exists(gen)):
+            raise
 
 
 def _cpu_has(*flags: str) -> bool:
@@ -52,8 +58,7 @@ def _load():
         return _lib
     name = "libgj_oracle.so" if _cpu_has("avx2", "fma") else "libgj_oracle_generic.so"
     path = os.path.join(_HERE, name)
-    if not os.path.exists(path):
-        build()
+    build()
     lib = ctypes.CDLL(path)
     fp = ctypes.POINTER(ctypes.c_float)
     ip = ctypes.POINTER(ctypes.c_int)

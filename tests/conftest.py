@@ -18,7 +18,34 @@ def pytest_configure(config):
 
 
 def golden_files():
-    return sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+    """(input, float64 inverse) fixtures; the mirror_digest_* files are a different kind (see below)."""
+    return sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+                  if not os.path.basename(p).startswith("mirror_digest_"))
+
+
+def load_mirror_digest(n):
+    """Digest of the oracle's blocked mirror on gate_matrix(n, seed), written by
+    tests/golden/make_mirror_digests.py in the build container: plan (widths, bw), sha256 of the
+    fp32 output bytes, 4096 sampled entries, per-row sums of |x|."""
+    d = np.load(os.path.join(GOLDEN, f"mirror_digest_N{n}.npz"), allow_pickle=False)
+    return {k: d[k] for k in d.files}
+
+
+def check_against_mirror_digest(x, dig):
+    """Bit-exact comparison of a flat fp32 result with a mirror digest; on a mismatch the assertion
+    message says how many sampled entries differ and which rows' |x| sums are off."""
+    import hashlib
+
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    n = int(dig["n"])
+    assert x.size == n * n
+    got = hashlib.sha256(x.tobytes()).digest()
+    if got == bytes(dig["sha256"]):
+        return
+    bad = int((x[dig["idx"]] != dig["vals"]).sum())
+    rows = np.nonzero(np.abs(x.reshape(n, n).astype(np.float64)).sum(axis=1) != dig["rowsum_abs"])[0]
+    raise AssertionError(f"N={n}: sha256 differs from the mirror's; {bad}/{dig['idx'].size} sampled entries differ, "
+                         f"{rows.size} rows differ (first {rows[:8].tolist()})")
 
 
 def load_golden(path):

@@ -183,3 +183,39 @@ def test_sharded_batch_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_makefile_prerequisites_cover_every_included_header():
+    """lib/libmat_inv_32.so is git-ignored yet shipped to the GPU box: a header-only edit that does not
+    rebuild it would let the parity tests validate a stale binary.  Every `#include "..."` of the HIP
+    sources (and of the headers they include) must be a prerequisite of the library target."""
+    csrc = _lib.CSRC_DIR
+    out = subprocess.run(["make", "-C", csrc, "-pn", "all"], capture_output=True, text=True).stdout
+    m = re.search(r"^\.\./lib/libmat_inv_32\.so:(.*)$", out, re.M)
+    assert m, "library rule not found in `make -pn`"
+    prereq = {os.path.normpath(os.path.join(csrc, p)) for p in m.group(1).split()}
+    seen, todo = set(), [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hip")]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(f).read(), re.M):
+            for base in (os.path.dirname(f), os.path.join(ROOT, "include")):
+                cand = os.path.normpath(os.path.join(base, inc))
+                if os.path.exists(cand):
+                    todo.append(cand)
+                    break
+            else:
+                raise AssertionError(f"{f} includes {inc}: not found")
+    missing = {os.path.normpath(f) for f in seen} - prereq
+    assert not missing, f"not prerequisites of the library: {sorted(missing)}"
+    # and the oracle: `make` decides staleness (oracle.build() always calls it)
+    o = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-pn", "all"], capture_output=True, text=True).stdout
+    assert re.search(r"^libgj_oracle\.so:.*gj_oracle\.c.*gj_oracle\.h", o, re.M)
+
+
+def test_status_codes_and_boundary_rule_are_documented():
+    """include/mat_inv_32_c.h states the invalid-matrix rule the tests hold both paths to."""
+    h = open(os.path.join(ROOT, "include", "mat_inv_32_c.h")).read()
+    assert "non-finite entry" in h and "NaN-filled" in h

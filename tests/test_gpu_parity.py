@@ -15,7 +15,8 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, forward_tolerance, gate_matrix, golden_files, load_golden, rel_err
+from conftest import (ROOT, check_against_mirror_digest, forward_tolerance, gate_matrix, golden_files, load_golden,
+                      load_mirror_digest, rel_err)
 
 pytestmark = pytest.mark.gpu
 
@@ -206,17 +207,52 @@ def test_batched_with_a_singular_member(oracle, inv_sweep, inv_blocked):
     assert oracle.residual_inf(mats[5], out[5], n) < 1e-4
 
 
-def test_nan_input_is_flagged_not_chosen(inv_sweep, inv_blocked):
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf], ids=["nan", "inf", "-inf"])
+def test_nonfinite_input_is_status_singular_on_both_paths(oracle, inv_sweep, inv_blocked, bad):
+    """The boundary rule (README.md:54 "in case of invalid matrix an empty vector is returned"): a non-finite
+    entry anywhere in the input, like a zero / NaN / infinite pivot, is status 2 on BOTH paths -- exactly the
+    oracle's status -- and `{}` from matrix_inv_32."""
     n = 40
-    a = gate_matrix(n, 77)
-    a[5, 5] = np.nan
+    for pos in ((5, 5), (0, 39), (39, 0)):
+        a = gate_matrix(n, 77)
+        a[pos] = bad
+        want = oracle.matrix_inv_32(a, n, return_info=True)[1]["status"]
+        assert want == oracle.STATUS_SINGULAR
+        for inv in (inv_sweep, inv_blocked):
+            _, st = run(inv, a)
+            assert st[0] == want, (pos, bad)
+        assert g.matrix_inv_32(a.reshape(-1), n).size == 0
+    # fp64 twin
+    a = gate_matrix(n, 78).astype(np.float64)
+    a[3, 9] = bad
+    _, st = inv_sweep.inv(torch.from_numpy(a).cuda())
+    assert int(st[0]) == oracle.matrix_inv_64(a, n, return_info=True)[1]["status"] == oracle.STATUS_SINGULAR
+    assert g.matrix_inv_64(a.reshape(-1), n).size == 0
+
+
+def test_zero_and_rank_deficient_are_status_singular(oracle, inv_sweep, inv_blocked):
+    n = 40
+    for a in (np.zeros((n, n), np.float32), np.ones((n, n), np.float32)):
+        want = oracle.matrix_inv_32(a, n, return_info=True)[1]["status"]
+        for inv in (inv_sweep, inv_blocked):
+            _, st = run(inv, a)
+            assert st[0] == want == oracle.STATUS_SINGULAR
+    # an overflowing pivot chain: huge entries make an infinite intermediate -> flagged, never "OK with inf"
+    a = gate_matrix(n, 79) * np.float32(3e38)
     for inv in (inv_sweep, inv_blocked):
-        _, st = run(inv, a)
-        assert st[0] in (0, 2)  # a NaN can never win a pivot search; it poisons the result instead
-    z = np.zeros((n, n), np.float32)
-    for inv in (inv_sweep, inv_blocked):
-        _, st = run(inv, z)
-        assert st[0] == 2
+        x, st = run(inv, a)
+        assert st[0] == oracle.STATUS_SINGULAR or np.isfinite(x).all()
+
+
+def test_a_batch_keeps_valid_members_when_one_is_nonfinite(oracle, inv_blocked):
+    n, B = 96, 5
+    mats = np.stack([gate_matrix(n, 950 + b) for b in range(B)])
+    mats[2, 10, 11] = np.nan
+    got, st = run(inv_blocked, mats)
+    assert list(st) == [0, 0, 2, 0, 0]
+    w, bw = inv_blocked.resolved_panel_widths(n, B), inv_blocked.resolved_blocking(n, B)[1]
+    for b in (0, 1, 3, 4):
+        assert np.array_equal(got[b].reshape(-1), oracle.matrix_inv_32_blocked2(mats[b], n, w, bw))
 
 
 @pytest.mark.parametrize("n", [1, 2, 5, 64, 100, 257, 700])
@@ -358,11 +394,98 @@ def test_blocked_2300_unfused_then_fused_blocks_bit_identical_to_mirror(oracle, 
     assert st[0] == 0 and np.array_equal(got.reshape(-1), want)
 
 
+def _default_inverter():
+    return g.Inverter(algo="auto")   # what matrix_inv_32 runs: AUTO plan, look-ahead on
+
+
+def test_c1_4096_default_plan_bit_identical_to_mirror(oracle):
+    """BASELINE configs[1] itself: N = 4096, the default plan (bw 256, W 16; four rows per lane in the unfused
+    panels of the first half, fused launches in the second, look-ahead halves on the second stream) against the
+    oracle's blocked mirror run live on this box, and against the digest of that mirror committed from the build
+    container (tests/golden/make_mirror_digests.py)."""
+    dig = load_mirror_digest(4096)
+    n, seed = 4096, int(dig["seed"])
+    a = gate_matrix(n, seed)
+    inv = _default_inverter()
+    try:
+        assert inv.resolved_algo(n, 1) == g.ALGO_BLOCKED
+        widths, bw = inv.resolved_panel_widths(n, 1), inv.resolved_blocking(n, 1)[1]
+        assert widths == dig["widths"].tolist() and bw == int(dig["bw"]), "plan changed: regenerate the digests"
+        got, st = run(inv, a)
+        inv.set_lookahead(False)          # the single-stream schedule must give the same bits
+        got1, st1 = run(inv, a)
+    finally:
+        inv.close()
+    want = oracle.matrix_inv_32_blocked2(a, n, widths, bw)
+    assert st[0] == 0 and st1[0] == 0
+    assert np.array_equal(got.reshape(-1), want)
+    assert np.array_equal(got1.reshape(-1), want)
+    check_against_mirror_digest(got, dig)
+
+
+@pytest.mark.parametrize("n", [8200, 16384])
+def test_shared_panel_sizes_bit_identical_to_mirror_digest(n):
+    """N = 8200 (8320 padded rows: three workgroups share the first panels) and N = 16384 = BASELINE configs[4]
+    (four workgroups, bw = 512): bit-exact against the digest of the oracle's blocked mirror (sha256 of all N^2
+    outputs + 4096 sampled entries + per-row |x| sums; the mirror takes minutes on a CPU, so it ran in the build
+    container: tests/golden/make_mirror_digests.py)."""
+    dig = load_mirror_digest(n)
+    a = gate_matrix(n, int(dig["seed"]))
+    inv = _default_inverter()
+    try:
+        widths, bw = inv.resolved_panel_widths(n, 1), inv.resolved_blocking(n, 1)[1]
+        assert widths == dig["widths"].tolist() and bw == int(dig["bw"]), "plan changed: regenerate the digests"
+        got, st = run(inv, a)
+    finally:
+        inv.close()
+    assert st[0] == 0
+    check_against_mirror_digest(got, dig)
+
+
+def test_8200_live_mirror(oracle):
+    """The same N = 8200 comparison against the mirror run live on this box (1.1 TFLOP of CPU work on the
+    oracle's AVX2/OpenMP build): no dependence on a committed digest."""
+    n = 8200
+    a = gate_matrix(n, 50_001)
+    inv = _default_inverter()
+    try:
+        widths, bw = inv.resolved_panel_widths(n, 1), inv.resolved_blocking(n, 1)[1]
+        got, st = run(inv, a)
+    finally:
+        inv.close()
+    want = oracle.matrix_inv_32_blocked2(a, n, widths, bw)
+    assert st[0] == 0 and np.array_equal(got.reshape(-1), want)
+
+
 def test_three_workgroup_panel_8200(inv_blocked):
-    """N = 8200 (8320 padded rows): the first sub-panels are shared by three workgroups.  Too large for the
-    CPU oracle in a test: the size-independent exact properties and the residual gate instead."""
+    """N = 8200 (8320 padded rows): the first sub-panels are shared by three workgroups: the size-independent
+    exact properties and the residual gate (bit-exactness: the two tests above)."""
     r = _full_size_properties(inv_blocked, 8200, 1, 50_000)
     print("8200 (three-workgroup panel) residual", r)
+
+
+def test_shared_panel_lost_partner_is_flagged_and_poisoned(inv_blocked):
+    """The time-out path of the shared panels.  MI32_DEBUG_DROP_PANEL_GROUP=1 (host side only) never launches
+    the last workgroup of a shared panel -- what a foreign kernel holding the CUs would cause.  The present
+    workgroup must give the partner up after a bounded wait, flag the matrix MI32_RUNTIME_ERROR, every later
+    launch must skip it, and the caller must get NaN, not numbers.  The next call is healthy again."""
+    n = 4200   # 4224 padded rows: two workgroups share the first panels
+    a = gate_matrix(n, 40_000)
+    inv = g.Inverter(algo="blocked")
+    try:
+        os.environ["MI32_DEBUG_DROP_PANEL_GROUP"] = "1"
+        try:
+            x, st = run(inv, a)
+        finally:
+            del os.environ["MI32_DEBUG_DROP_PANEL_GROUP"]
+        assert st[0] == _lib.MI32_RUNTIME_ERROR
+        assert np.isnan(x).all()
+        x2, st2 = run(inv, a)
+        assert st2[0] == 0 and np.isfinite(x2).all()
+        ta, tx = torch.from_numpy(a).cuda(), torch.from_numpy(x2).cuda()
+        assert float(inv.residual(ta, tx)[0, 0]) < 1e-3
+    finally:
+        inv.close()
 
 
 def test_sweep_2048_bit_identical_to_oracle(oracle, inv_sweep):
@@ -373,9 +496,32 @@ def test_sweep_2048_bit_identical_to_oracle(oracle, inv_sweep):
     assert st[0] == 0 and np.array_equal(got.reshape(-1), want)
 
 
-def test_c2_batch_of_2048(inv_blocked):
+def test_c2_real_shape_64_x_2048(oracle):
+    """BASELINE configs[2] at its real shape: 64 x 2048^2 on one GPU, default plan -> outer block width 128 and the
+    two-stream batch split (32 + 32).  Residual gate on all 64, the exact size-independent properties on the whole
+    batch, and bit-exactness against the oracle's blocked mirror for four of the 64 (two from each half)."""
+    n, B = 2048, 64
+    inv = _default_inverter()
+    try:
+        assert inv.resolved_algo(n, B) == g.ALGO_BLOCKED
+        widths, bw = inv.resolved_panel_widths(n, B), inv.resolved_blocking(n, B)[1]
+        assert bw == 128 and set(widths) == {16}
+        res = _full_size_properties(inv, n, B, 30_000)
+        print("C2 (64 x 2048^2) worst residual", res)
+        mats = torch.from_numpy(np.stack([gate_matrix(n, 30_000 + i) for i in range(B)])).cuda()
+        x, st = inv.inv(mats)
+        torch.cuda.synchronize()
+        assert int(st.max()) == 0
+        for b in (0, 31, 32, 63):
+            want = oracle.matrix_inv_32_blocked2(gate_matrix(n, 30_000 + b), n, widths, bw)
+            assert np.array_equal(x[b].cpu().numpy().reshape(-1), want), b
+    finally:
+        inv.close()
+
+
+def test_c2_subset_8_of_2048(inv_blocked):
     r = _full_size_properties(inv_blocked, 2048, 8, 30_000)
-    print("C2 (8 of the 64) residual", r)
+    print("8 x 2048^2 (bw 256, unsplit) residual", r)
 
 
 def test_split_batch_is_bit_identical_to_the_unsplit_batch(inv_blocked):
@@ -404,7 +550,8 @@ def test_split_batch_is_bit_identical_to_the_unsplit_batch(inv_blocked):
 
 def test_c4_single_16384_maximum_size(inv_blocked):
     """C4 = the largest order the blocked path takes (four-workgroup panel for the first 12288 pivots).  The fp64
-    residual product is done by torch (checker only, 8.8 TFLOP); plus the exact power-of-two scaling property."""
+    residual product is done by torch (checker only, 8.8 TFLOP); plus the exact power-of-two scaling property.
+    (Bit-exactness against the oracle: test_shared_panel_sizes_bit_identical_to_mirror_digest.)"""
     n = 16384
     a = torch.from_numpy(gate_matrix(n, 70_000)).cuda()
     x, st = inv_blocked.inv(a)
@@ -418,3 +565,50 @@ def test_c4_single_16384_maximum_size(inv_blocked):
     res = float(r.abs().sum(dim=1).max())
     print("C4 residual", res)
     assert res < 1e-3, res
+
+
+def test_host_pointer_entry_points_are_thread_safe(oracle):
+    """matrix_inv_32 and matrix_inversion_FP64 (host-pointer twins) share the default context's staging buffers:
+    two threads calling them concurrently, with sizes that force the buffers to grow, must each get exactly the
+    single-threaded answer (one mutex serialises all host-pointer entry points)."""
+    import threading
+
+    jobs32 = [(n, gate_matrix(n, 600 + n)) for n in (64, 300, 150, 520, 90)]
+    jobs64 = [(n, gate_matrix(n, 700 + n).astype(np.float64)) for n in (200, 50, 410, 120, 330)]
+    want32 = [g.matrix_inv_32(a.reshape(-1), n).copy() for n, a in jobs32]
+    want64 = [g.matrix_inv_64(a.reshape(-1), n).copy() for n, a in jobs64]
+    errors = []
+
+    def worker(fn, jobs, want):
+        try:
+            for _ in range(6):
+                for (n, a), w in zip(jobs, want):
+                    got = fn(a.reshape(-1), n)
+                    if not np.array_equal(got, w):
+                        errors.append((fn.__name__, n))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(g.matrix_inv_32, jobs32, want32)),
+          threading.Thread(target=worker, args=(g.matrix_inv_64, jobs64, want64)),
+          threading.Thread(target=worker, args=(g.matrix_inv_32, jobs32[::-1], want32[::-1]))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
+    total, compute = g.last_timing()
+    assert total >= compute > 0
+
+
+def test_device_call_without_status_buffer(inv_blocked):
+    """d_status = NULL is allowed by the C ABI: the context keeps the status words itself."""
+    n = 200
+    a = torch.from_numpy(gate_matrix(n, 12)).cuda()
+    want, _ = inv_blocked.inv(a)
+    out = torch.empty_like(a)
+    inv_blocked._bind_stream()
+    rc = inv_blocked._lib.mi32_inv_device(inv_blocked._h, ctypes.c_void_p(a.data_ptr()), n, 1,
+                                          ctypes.c_void_p(out.data_ptr()), None)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(out, want)

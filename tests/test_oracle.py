@@ -38,6 +38,79 @@ def test_reference_script_fixture_is_reference_output():
         assert a64.min() >= 0.0 and a64.max() <= 100.0  # U(0,100), matrix_inv_numpy.py:40
 
 
+@pytest.mark.parametrize("K", [8, 64, 256])
+def test_oracle_matches_the_reference_scripts_own_output(oracle, K):
+    """The direct pin: the oracle, fed the fp32 cast of the matrix the reference's just_inv(K) built
+    (matrix_inv_numpy.py:40-41), against the inverse the reference itself computed from the float64
+    matrix (matrix_inv_numpy.py:44; captured by tests/golden/make_golden.py).  Tolerance: the fp32
+    forward bound 2 kappa_inf 2^-24 for the oracle's own rounding plus kappa_inf 2^-24 for the fp32
+    cast of the input (|dA| <= 2^-24 |A| moves the exact inverse by <= kappa 2^-24 relative)."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"ref_just_inv_K{K}.npz"))
+    a, ref_out = d["a"], d["inv64_of_a64"]
+    x, info = oracle.matrix_inv_32(a, K, return_info=True)
+    assert info["status"] == oracle.STATUS_OK
+    assert rel_err(x, ref_out) <= forward_tolerance(a, factor=3.0)
+    # and every other restatement the GPU paths are compared with, against the same reference output
+    for y in (oracle.matrix_inv_32_inplace(a, K), oracle.matrix_inv_32_blocked2(a, K, 16, 256)):
+        assert rel_err(y, ref_out) <= forward_tolerance(a, factor=3.0)
+
+
+def test_nonfinite_input_and_bad_pivots_are_status_singular(oracle):
+    """The boundary rule (README.md:54): a zero / NaN / infinite pivot, or any non-finite input entry,
+    is an invalid matrix -> status SINGULAR from every restatement (the HIP paths are held to the same)."""
+    n = 40
+    base = gate_matrix(n, 77)
+    cases = {"nan": np.nan, "inf": np.inf, "-inf": -np.inf}
+    for name, v in cases.items():
+        a = base.copy()
+        a[5, 7] = v
+        for fn in (lambda m: oracle.matrix_inv_32(m, n, return_info=True),
+                   lambda m: oracle.matrix_inv_32_inplace(m, n, return_info=True),
+                   lambda m: oracle.matrix_inv_32_blocked2(m, n, 16, 256, return_info=True)):
+            assert fn(a)[1]["status"] == oracle.STATUS_SINGULAR, name
+        _, info = oracle.matrix_inv_64(a.astype(np.float64), n, return_info=True)
+        assert info["status"] == oracle.STATUS_SINGULAR
+    for a in (np.zeros((n, n), np.float32), np.ones((n, n), np.float32)):
+        assert oracle.matrix_inv_32(a, n, return_info=True)[1]["status"] == oracle.STATUS_SINGULAR
+    assert oracle.matrix_inv_32(base, n, return_info=True)[1]["status"] == oracle.STATUS_OK
+
+
+def test_fast_and_portable_oracle_builds_are_bit_identical(oracle):
+    """libgj_oracle.so runs the blocked mirrors' rank-k updates 64 elements at a time on AVX2 FMA lanes
+    and over OpenMP threads; libgj_oracle_generic.so one element at a time through libm's fmaf.  Every
+    output element is its own k-ascending fmaf chain either way: same bits."""
+    import ctypes
+
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    libs = [ctypes.CDLL(os.path.join(here, nm)) for nm in ("libgj_oracle.so", "libgj_oracle_generic.so")]
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+    for n, bw, w in ((130, 128, 16), (300, 256, 8), (700, 256, 16), (1100, 512, 32)):
+        a = np.ascontiguousarray(gate_matrix(n, 5 * n).reshape(-1))
+        ws = np.full(16, w, np.int32)
+        outs = []
+        for lib in libs:
+            lib.gjo_matrix_inv_32_blocked2w.restype = ctypes.c_int
+            lib.gjo_matrix_inv_32_blocked2w.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ip, ctypes.c_int,
+                                                        ctypes.c_int, ip]
+            out = np.empty(n * n, np.float32)
+            assert lib.gjo_matrix_inv_32_blocked2w(a.ctypes.data_as(fp), a.size, n, out.ctypes.data_as(fp),
+                                                   ws.ctypes.data_as(ip), ws.size, bw, None) == 0
+            outs.append(out)
+        assert np.array_equal(outs[0], outs[1]), (n, bw, w)
+
+
+def test_mirror_digest_4096_reproduced_here(oracle):
+    """The committed digest of the blocked mirror at N = 4096 (tests/golden/make_mirror_digests.py) is
+    reproduced by whatever oracle build runs on this machine: the mirror the GPU tests compare with is
+    the same function of its input everywhere."""
+    from conftest import check_against_mirror_digest, load_mirror_digest
+
+    dig = load_mirror_digest(4096)
+    a = gate_matrix(4096, int(dig["seed"]))
+    x = oracle.matrix_inv_32_blocked2(a, 4096, dig["widths"].tolist(), int(dig["bw"]))
+    check_against_mirror_digest(x, dig)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 16, 33, 64, 100, 130, 257])
 def test_inplace_form_is_bit_identical_to_augmented(oracle, n):
     """The N x N in-place layout the HIP kernels use stores exactly the values of the
