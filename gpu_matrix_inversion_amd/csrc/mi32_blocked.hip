@@ -466,7 +466,12 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
         }
         if (wave_u == 0 && lane < W) sh.prn_all[R][lane] = __uint_as_float(sh.gx[par][gw][lane]);
     }
-    const int p = (int)(0xFFFFFu - (lo >> 8));
+    int p = (int)(0xFFFFFu - (lo >> 8));
+    if constexpr (MULTI) {
+        // no record at all (only after a partner was lost and this workgroup has no candidate left): keep the
+        // label a valid position -- nothing out of range may ever reach the row maps
+        if (key == 0ull) p = slot;
+    }
     const int wv = MULTI ? (int)(lo & 0xFu) : (int)(lo & 0xFFu);
     if (key == 0ull) singular = true;  // cannot happen (position `slot` is always a live candidate); never trust it
     if constexpr (!MULTI) {
