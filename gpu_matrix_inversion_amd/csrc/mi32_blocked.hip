@@ -244,6 +244,19 @@ __global__ __launch_bounds__(256) void blocked_init_kernel(const float *__restri
     if (nonfinite && status) status[b] = MI32_SINGULAR;
 }
 
+// Diagnostic builds (make stamps -> lib/libmat_inv_32_stamps.so, tools/panel_stamps.py) record s_memtime at the
+// phase boundaries of every panel launch (wave 0 of workgroup 0); in the product build the macro expands to nothing.
+#ifdef MI32_PANEL_STAMPS
+__device__ unsigned long long *g_panel_stamps;  // [1024 launches][64 slots]
+#define MI32_PSTAMP(TAG_, SLOT_)                                                                             \
+    do {                                                                                                     \
+        if (g_panel_stamps && threadIdx.x == 0 && blockIdx.x == 0)                                           \
+            g_panel_stamps[(size_t)((TAG_) & 1023u) * 64 + (SLOT_)] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
+#else
+#define MI32_PSTAMP(TAG_, SLOT_) do { } while (0)
+#endif
+
 // ---- wave-level arg-max helpers (DPP, no LDS traffic) ----------------------------
 // Canonical gfx9 wave64 reduction: quad_perm x2, row_half_mirror, row_mirror, then
 // row_bcast15 / row_bcast31 fold the four rows; lane 63 ends up with the total.  Each stage
@@ -348,11 +361,15 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
     int lane;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
 
+    constexpr bool kSub = (R == W / 2);  // diagnostic builds: phase stamps inside one representative step
+    if (kSub) MI32_PSTAMP(pg.tag_base, 32);
     // -- maxPivot over this lane's rows
     float col[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) col[k] = a[k][R];
     int own_lane = -1, own_k = 0;
+    bool cand_bad = false;  // this wave's candidate has a zero / NaN / infinite pivot entry
+    float qv = 0.0f;        // lanes 0..W-1: this wave's candidate row, normalised (kept for the export if it wins)
     if (wave_active) {
         unsigned mkey = 0u, mnp = 0u;
         int kb = 0;
@@ -365,7 +382,9 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
             mnp = better ? npl[k] : mnp;
             kb = better ? k : kb;
         }
+        if (kSub) MI32_PSTAMP(pg.tag_base, 33);
         const unsigned wm = wave_max_u32(mkey);
+        if (kSub) MI32_PSTAMP(pg.tag_base, 34);
         // lanes that hold the wave maximum and a real candidate: almost always exactly one
         unsigned long long hit = __ballot(mkey == wm && (int)mnp < 0);
         if (hit != 0ull) {  // this wave has a candidate
@@ -388,6 +407,7 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
                                 make_float4(a[k][c], a[k][c + 1], a[k][c + 2], a[k][c + 3]);
                     }
                 }
+            if (kSub) MI32_PSTAMP(pg.tag_base, 35);
             // fixRow, speculatively: lanes 0..W-1 divide one element each (IEEE); identity entry -> 1/piv.
             // One wave's LDS operations execute in order, so no s_barrier is needed between the holder
             // lane's store and these loads -- only the compiler must not reorder here.
@@ -395,16 +415,26 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
             __builtin_amdgcn_wave_barrier();
             const float cpiv = sh.cand[wave_u][R];
             const float num = (lane < W) ? ((lane == R) ? 1.0f : sh.cand[wave_u][lane]) : 0.0f;
-            const float qv = num / cpiv;
+            if (kSub) MI32_PSTAMP(pg.tag_base, 36);
+            qv = num / cpiv;
+            cand_bad = (cpiv == 0.0f || cpiv - cpiv != 0.0f);
+            if (kSub) MI32_PSTAMP(pg.tag_base, 37);
             if (lane < W) sh.prn[par][wave_u][lane] = qv;
             if (lane == 0)
                 atomicMax(&sh.key[R], ((unsigned long long)wm << 32) |
                                           (unsigned long long)(((0xFFFFFu - wi) << 8) | (unsigned)wave_u));
         }
     }
+    if (kSub) MI32_PSTAMP(pg.tag_base, 38);
     __syncthreads();
+    if (kSub) MI32_PSTAMP(pg.tag_base, 39);
+    // (Tried: reading every wave's candidate in the same LDS round as the arg-max word and picking the winner's W
+    // entries out of their lanes with v_readlane into SGPRs -- no dependent second read, no spills in the 128-VGPR
+    // instances.  16 v_readlane per wave and step cost more than the LDS round trip they replace once 2 or 4
+    // waves share a SIMD: 2905 -> 3556 cycles per step at 4096 rows, 1876 -> 1800 with one wave per SIMD.)
     unsigned long long key = sh.key[R];
     unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(key & 0xFFFFFFFFull));
+    if (kSub) MI32_PSTAMP(pg.tag_base, 40);
     float prn[W];  // prn[R] = 1/piv (the identity column's entry), prn[c] = normalised pivot row
     bool my_group_won = true;
     if constexpr (MULTI) {
@@ -481,6 +511,7 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
             prn[c] = t.x; prn[c + 1] = t.y; prn[c + 2] = t.z; prn[c + 3] = t.w;
         }
     }
+    if (kSub) { asm volatile("" ::"v"(prn[0]), "v"(prn[W - 1])); MI32_PSTAMP(pg.tag_base, 41); }
     // -- fixColumn on the slab, branch-free; the pivot column holds the implicit identity column, whose
     //    entry is 0 in every row but the pivot row.  The pivot row itself is overwritten right after.
 #pragma unroll
@@ -490,6 +521,7 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
         for (int c = 0; c < W; ++c)
             a[k][c] = (c == R) ? __builtin_fmaf(-f, prn[R], 0.0f) : __builtin_fmaf(-f, prn[c], a[k][c]);
     }
+    if (kSub) { asm volatile("" ::"v"(a[0][0]), "v"(a[RPT - 1][W - 1])); MI32_PSTAMP(pg.tag_base, 42); }
     // -- pivotElements == exchange of two position labels: the row that held `slot` takes p ...
     if (p != slot) {
 #pragma unroll
@@ -498,10 +530,10 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
     // ... and the winner's candidate row (its wave knows lane and row) becomes the pivot row: normalised
     // values, label `slot`, no longer a candidate
     if (my_group_won && wave_u == wv) {
-        // this wave's scratch slot still holds the winning row as found: its pivot entry decides "singular"
-        const float cpiv = sh.cand[wave_u][R];
-        if (cpiv == 0.0f || cpiv - cpiv != 0.0f) singular = true;  // zero, NaN or infinite pivot
-        if (!MULTI && lane < W) sh.prn_all[R][lane] = sh.prn[par][wv][lane];
+        // the winner's own pivot entry decides "singular" (zero, NaN or infinite pivot); its normalised row is
+        // still in lanes 0..W-1 -- no LDS read on the slowest wave's way to the next barrier
+        if (cand_bad) singular = true;
+        if (!MULTI && lane < W) sh.prn_all[R][lane] = qv;
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (own_k == k) {
@@ -512,6 +544,7 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
                 }
             }
     }
+    MI32_PSTAMP(pg.tag_base, 3 + R);
 }
 
 template <int NT, int RPT, int W, bool MULTI, int... Rs>
@@ -595,6 +628,7 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     const int *invsub_prev = A.invsub_prev + (size_t)b * np;
     if (tid < W) sh.key[tid] = 0ull;
     if (tid == 0) sh.lost = 0;
+    MI32_PSTAMP(A.tag_base, 0);
 
     // -- the slab and every row's label at entry (its position after the previous sub-panel's swaps)
     float a[RPT][W];
@@ -639,6 +673,10 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     if (A.first_in_block && grp == 0)
         for (int i = tid; i < row_lo; i += NT) rowsrc[i] = i;
 
+#ifdef MI32_PANEL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MI32_PSTAMP(A.tag_base, 1);
     if (has_prev) {
         // -- update(s-1) on this sub-panel's columns, which nobody has applied yet:
         //      a[row][c] = (row is a pivot row of s-1 ? 0 : a[row][c]) + sum_k G_{s-1}[row][k] * B[k][c],
@@ -696,6 +734,7 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     bool singular = false;
     __syncthreads();  // sh.key[] zeroed before any wave's first atomicMax; all map reads issued
     PanelGroup pg = {A.ngroups, grp, A.xch + (size_t)b * kXchGranules, A.tag_base, false};
+    MI32_PSTAMP(A.tag_base, 2);
     panel_steps<NT, RPT, W, MULTI>(a, npl, sh, wave_u, c0, true, singular, pg, std::make_integer_sequence<int, W>{});
     int pos[RPT];  // final position of every register row
 #pragma unroll
@@ -704,6 +743,7 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     // -- for the rows above the block (update(s) computes their G_s): the W normalised pivot rows, and the
     //    pivot rows of s-1 restricted to this sub-panel's columns
     __syncthreads();
+    MI32_PSTAMP(A.tag_base, 48);
     float *aux = A.aux_out + (size_t)b * (2 * kMaxW * kMaxW);
     if (grp == 0)
         for (int i = tid; i < W * W; i += NT) {
@@ -753,6 +793,16 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
         }
     }
     // only the wave that won a step has looked at that step's pivot: any wave may raise the flag
+#ifdef MI32_PANEL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MI32_PSTAMP(A.tag_base, 49);
+    if (g_panel_stamps && threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long *q = g_panel_stamps + (size_t)(A.tag_base & 1023u) * 64;
+        q[50] = __builtin_amdgcn_s_memrealtime();
+        q[51] = ((unsigned long long)NT << 32) | ((unsigned)RPT << 16) | ((unsigned)(FUSED ? 1 : 0) << 8) | (unsigned)W;
+        q[52] = (unsigned long long)(np - row_lo);
+    }
+#endif
     // (atomicMax: a later "singular" must not hide "a partner workgroup never showed up")
     if (singular && lane == 0 && A.status) atomicMax(&A.status[b], (int)MI32_SINGULAR);
     if (pg.timed_out && lane == 0 && A.status) atomicMax(&A.status[b], (int)MI32_RUNTIME_ERROR);
@@ -1414,5 +1464,13 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     }
     return hipGetLastError();
 }
+
+#ifdef MI32_PANEL_STAMPS
+// diagnostic builds only: where the panel kernels write their stamps (device buffer of 1024 x 64 u64, or NULL)
+extern "C" int mi32_debug_panel_stamps(unsigned long long *dev_buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_panel_stamps), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : 3;
+}
+#endif
 
 }  // namespace mi32

@@ -77,9 +77,14 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL(gj_panel_transpose_kernel, dim3(np / 64, kdim / 64, batch), dim3(256), 0, 0, g, mstride, np, ld, c0, gk,
                            gkstride);
     };
+    CK(hipFuncSetAttribute((const void *)gj_rank_bw2_kernel<RB_BK, RB_WPS, RB_BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     auto run2 = [&]() {
         hipLaunchKernelGGL((gj_rank_bw2_kernel<RB_BK, RB_WPS, RB_BN>), dim3(T * (np / RB_BN), batch), dim3(256), lds2, 0, src, d2, g, mstride, gk,
-                           gkstride, np, ld, mstride, c0, kdim, map, 1, PanelExport{pt2, 0, pt_col, pt_w, 1}, tstride, 0, 0);
+                           gkstride, np, ld, mstride, c0, kdim, map, 1, PanelExport{pt2, 0, pt_col, pt_w, 1}, tstride, 0, 0, (const int *)nullptr);
+    };
+    auto run2old = [&]() {  // lane = column layout (first version of generation 2), for A/B
+        hipLaunchKernelGGL((gj_rank_bw2_kernel<RB_BK, RB_WPS, RB_BN>), dim3(T * (np / RB_BN), batch), dim3(256), lds2, 0, src, d2, g, mstride, gk,
+                           gkstride, np, ld, mstride, c0, kdim, map, 1, PanelExport{pt2, 0, pt_col, pt_w, 1}, tstride, 0, 0, (const int *)nullptr);
     };
     run1(); runT(); run2();
     CK(hipDeviceSynchronize());
@@ -136,7 +141,10 @@ int main(int argc, char **argv)
 #endif
     time_it("gen1 update", run1);
     time_it("gen2 transpose", runT);
-    time_it("gen2 update", run2);
+    for (int round = 0; round < 3; ++round) {  // interleaved A/B rounds in one process
+        time_it("gen2 update", run2old);
+        time_it("gen2 update (again)", run2);
+    }
     time_it("gen2 transpose+update", [&]() { runT(); run2(); });
     return bad != 0 || !pt_same;
 }
