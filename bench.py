@@ -12,17 +12,30 @@ matrices (independent units, no data-path collective): weak scaling.  Rank 0 pri
 line: value = matrices/s over all ranks = N * batch * K / T, T = max over ranks of the time of
 exactly K steps bracketed by barrier + torch.cuda.synchronize().
 
-Extra objects on the same line:
-  roofline      -- the dominant kernel's algorithmic FLOP/s (or B/s) per launch: launch
-                   durations come from HIP events recorded on the launch stream (inside the
-                   library, mi32_set_profiling) over a second, instrumented pass of the same K
-                   steps, so the un-instrumented pass that yields `value` is not perturbed.
-                   (That pass runs with the look-ahead split off, so that every rank-bw update
-                   is one full-size launch of the kernel the roofline is quoted for.)
-  cpu_baseline  -- numpy.linalg.inv (the reference's CPU path, matrix_inv_numpy.py:44, through
-                   our just_inv-shaped harness) on the same fp32 input on this box's host cores.
+Extra objects on the same line (SURVEY.md 8d):
+  roofline      -- the kernel that carries the algorithmic flops (or bytes): per-launch
+                   durations from HIP events recorded on the launch stream (inside the library,
+                   mi32_set_profiling) over a second, instrumented pass of the same K steps, so the
+                   un-instrumented pass that yields `value` is not perturbed.  (That pass runs with
+                   the look-ahead split off: every rank-bw update is one full-size launch of the
+                   kernel the roofline is quoted for.)  `traffic` comes from the rocprofv3 --pmc
+                   passes committed under profiles/ -- only from an entry whose (algo, n, batch,
+                   block width) matches this run.  `time_dominant` names the kernel class that takes
+                   most of the step when it is not the roofline kernel.
+  e2e           -- T_e2e: the same matrix through the host-pointer drop-in matrix_inv_32(vec, N)
+                   (pageable host memory both ways), the figure "x NumPy wall-clock" is defined on;
+                   the reference prints both timings too (mat_inv_32.cpp:385-386).
+  cpu_baseline  -- numpy.linalg.inv (the reference's CPU path, matrix_inv_numpy.py:44, through our
+                   just_inv-shaped harness) on the same fp32 input on this box's host cores: the
+                   best of a few BLAS thread counts (stated), plus the 1-thread number.
+  residuals     -- D_gate (gated at 1e-3) and, ungated, the reference's own input distributions
+                   D_ref100 = U(0,100) and D_rand = U(0,1) next to NumPy's residual on the same input.
+  distribution  -- with --distribute (N > 1): the batch starts on rank 0 only and is scattered /
+                   gathered over RCCL point-to-point sends; matrices/s including the transfers.
 """
 import argparse
+import contextlib
+import io
 import json
 import os
 import statistics
@@ -40,6 +53,7 @@ import numpy as np  # noqa: E402
 PUBLISHED_MATRICES_PER_S_N4096 = 1.0 / 2.92434
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round2", "pmc_traffic.json")
 
 
 def gate_matrix(n, seed):
@@ -49,44 +63,70 @@ def gate_matrix(n, seed):
     return a[rng.permutation(n)].astype(np.float32)
 
 
-def cpu_baseline(a, budget_s=20.0):
-    """numpy.linalg.inv on the same fp32 matrix, all host cores NumPy's BLAS uses; bounded."""
-    import gpu_matrix_inversion_amd as g
-
-    n = a.shape[0]
-    threads = os.cpu_count() or 1
-    blas = "unknown"
+def _blas_info():
     try:
         from threadpoolctl import threadpool_info
 
         info = [i for i in threadpool_info() if i.get("user_api") == "blas"]
         if info:
-            threads = int(info[0].get("num_threads", threads))
-            blas = f"{info[0].get('internal_api')} {info[0].get('version')}"
+            return int(info[0].get("num_threads", 0)), f"{info[0].get('internal_api')} {info[0].get('version')}"
     except Exception:
         pass
-    t0 = time.perf_counter()
-    np.linalg.inv(a)  # warm-up: BLAS thread-pool start-up
-    first = time.perf_counter() - t0
-    times = []
-    import contextlib
-    import io
+    return os.cpu_count() or 1, "unknown"
 
-    while len(times) < 5 and (sum(times) + first) < budget_s:
+
+def _time_numpy_inv(a, reps):
+    """Median seconds of numpy.linalg.inv(a) through the reference script's call shape (just_inv)."""
+    import gpu_matrix_inversion_amd as g
+
+    n = a.shape[0]
+    times = []
+    for _ in range(reps):
         with contextlib.redirect_stdout(io.StringIO()):
-            dt, _, _ = g.just_inv(n, inv=lambda m: np.linalg.inv(a))  # the reference script's call shape
+            dt, _, _ = g.just_inv(n, inv=lambda m: np.linalg.inv(a))
         times.append(dt)
-    med = statistics.median(times) if times else first
+    return statistics.median(times)
+
+
+def cpu_baseline(a, budget_s=40.0):
+    """numpy.linalg.inv on the same fp32 matrix: the best of a few BLAS thread counts and the 1-thread number
+    (a 64-thread OpenBLAS on a 256-CPU host is not automatically its fastest setting); bounded in time."""
+    n = a.shape[0]
+    max_threads, blas = _blas_info()
+    t_start = time.perf_counter()
+    np.linalg.inv(a)  # warm-up: BLAS thread-pool start-up
+    first = time.perf_counter() - t_start
+    sweep = {}
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    counts = [max_threads]
+    if threadpool_limits is not None:
+        counts = sorted({max_threads, max(1, max_threads // 2), min(max_threads, 16), min(max_threads, 8), 1}, reverse=True)
+    for c in counts:
+        if time.perf_counter() - t_start > budget_s and sweep:
+            break
+        ctx = threadpool_limits(limits=c, user_api="blas") if threadpool_limits is not None else contextlib.nullcontext()
+        with ctx:
+            np.linalg.inv(a)  # settle the pool at this size
+            reps = 3 if c > 1 else 1
+            sweep[c] = _time_numpy_inv(a, reps)
+    best_c = min((c for c in sweep if c > 1), key=lambda c: sweep[c], default=max(sweep))
+    med = sweep[best_c]
     return {
         "value": 1.0 / med,
         "unit": "matrices/s",
-        "cores": threads,
+        "cores": best_c,
         "kind": "reference",
         "what": "numpy.linalg.inv on the same fp32 input (the reference CPU path's call, "
-                "matrix_inv_numpy.py:44, via the just_inv-shaped harness)",
-        "sample": f"{len(times)} timed calls of one {n}x{n} fp32 inversion after 1 warm-up, median",
+                "matrix_inv_numpy.py:44, via the just_inv-shaped harness); best of the BLAS thread counts tried",
+        "sample": f"one {n}x{n} fp32 inversion, median of 3 timed calls per thread count after a warm-up "
+                  f"(first call of the process: {first:.2f} s)",
         "seconds_per_matrix": med,
         "gflops_2n3": 2.0 * n ** 3 / med / 1e9,
+        "seconds_by_blas_threads": {str(c): sweep[c] for c in sorted(sweep)},
+        "one_thread_seconds": sweep.get(1),
         "blas": blas,
         "numpy": np.__version__,
         "host_cpus": os.cpu_count(),
@@ -110,6 +150,45 @@ def oracle_port_baseline(n_small=1024):
         return {"error": repr(e)}
 
 
+def reference_distribution_residuals(inv, n, torch, dev, budget_s=25.0):
+    """||A X - I||_inf on the reference's own input distributions (ungated: fp32 Gauss-Jordan cannot reach 1e-3
+    there), ours next to NumPy's on the same matrix.  matrix_inv_pyopencl.py:17, matrix_inv_numpy.py:40
+    (U(0,100)) and the MATLAB live script's rand(N,N) (U(0,1))."""
+    out = {}
+    t_start = time.perf_counter()
+    for name, hi in (("D_ref100", 100.0), ("D_rand", 1.0)):
+        a = np.random.default_rng(4242).uniform(0.0, hi, (n, n)).astype(np.float32)
+        ta = torch.from_numpy(a).to(dev)
+        x, st = inv.inv(ta)
+        r = inv.residual(ta, x)
+        torch.cuda.synchronize()
+        entry = {"ours_residual_inf": float(r[0, 0]), "ours_residual_inf_left": float(r[0, 1]),
+                 "ours_frobenius_metric": float(r[0, 2]), "status": int(st[0])}
+        if time.perf_counter() - t_start < budget_s:
+            xn = np.linalg.inv(a)
+            rn = inv.residual(ta, torch.from_numpy(np.ascontiguousarray(xn, dtype=np.float32)).to(dev))
+            torch.cuda.synchronize()
+            entry["numpy_fp32_residual_inf"] = float(rn[0, 0])
+            entry["numpy_fp32_residual_inf_left"] = float(rn[0, 1])
+        out[name] = entry
+    return out
+
+
+def pmc_traffic(algo_name, n, batch, bw):
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes, only for the exact config."""
+    try:
+        table = json.load(open(PMC_TRAFFIC_FILE))
+    except Exception:
+        return None, None
+    key = f"{algo_name}_n{n}_b{batch}" + (f"_bw{bw}" if algo_name == "blocked" else "")
+    e = table.get(key)
+    if not e:
+        return None, None
+    return e.get("hbm_bytes_per_launch_corrected"), {"file": os.path.relpath(PMC_TRAFFIC_FILE, ROOT), "key": key,
+                                                     "fetch_bytes_x2": e.get("fetch_bytes_x2"),
+                                                     "write_bytes": e.get("write_bytes")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +201,8 @@ def main():
     ap.add_argument("--block-width", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--distribute", action="store_true",
+                    help="N > 1: also time the batch scattered from / gathered to rank 0 over RCCL (xGMI)")
     args = ap.parse_args()
 
     import torch
@@ -149,6 +230,7 @@ def main():
     inv.reserve(n, batch)
     algo_id = inv.resolved_algo(n, batch)
     algo_name = {g.ALGO_SWEEP: "sweep", g.ALGO_BLOCKED: "blocked"}[algo_id]
+    bw = inv.resolved_blocking(n, batch)[1] if algo_id == g.ALGO_BLOCKED else 0
 
     def sync_all():
         torch.cuda.synchronize()
@@ -176,7 +258,43 @@ def main():
     torch.cuda.synchronize()
     res_right = float(res[:, 0].max())
     res_left = float(res[:, 1].max())
+    res_frob = float(res[:, 2].abs().max())
     st_max = int(status.max())
+
+    # with distribution: the whole batch starts on rank 0, travels over RCCL point-to-point sends
+    distribution = None
+    if args.distribute and world > 1:
+        full = None
+        if rank == 0:
+            full = torch.cat([a] + [torch.from_numpy(np.stack([gate_matrix(n, 1000 + r * batch + b) for b in range(batch)])).to(dev)
+                                    for r in range(1, world)])
+        bufs = {}
+        tm_sum = {"scatter": 0.0, "compute": 0.0, "gather": 0.0}
+        for i in range(args.warmup + args.steps):
+            if i == args.warmup:
+                sync_all()
+                td0 = time.perf_counter()
+            _, _, worst, tm = g.invert_distributed(full, lambda s: inv.inv(s), root=0, shard_buffers=bufs)
+            if i >= args.warmup:
+                for k in tm_sum:
+                    tm_sum[k] += tm[k]
+        torch.cuda.synchronize()
+        d_elapsed = time.perf_counter() - td0
+        dist.barrier()
+        t = torch.tensor([d_elapsed] + [tm_sum[k] for k in ("scatter", "compute", "gather")], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d_elapsed = float(t[0])
+        distribution = {
+            "with_distribution_matrices_per_s": world * batch * args.steps / d_elapsed,
+            "ms_per_step": 1e3 * d_elapsed / args.steps,
+            "scatter_ms_per_step": 1e3 * float(t[1]) / args.steps,
+            "compute_ms_per_step": 1e3 * float(t[2]) / args.steps,
+            "gather_ms_per_step": 1e3 * float(t[3]) / args.steps,
+            "worst_status": worst,
+            "bytes_scattered_per_step": (world - 1) * batch * n * n * 4,
+            "transport": "torch.distributed batch_isend_irecv on nccl (= grouped ncclSend/ncclRecv over xGMI), root = rank 0",
+        }
+        del full
 
     # instrumented pass: HIP events around every launch, on the launch stream
     roof = None
@@ -196,42 +314,65 @@ def main():
         inv.set_lookahead(True)
         breakdown = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
                          "avg_us": (1e3 * v[0] / v[1]) if v[1] else None} for k, v in prof.items() if v[1]}
-        # the roofline object below is for the kernel that carries the algorithmic flops (the fp32-MFMA
-        # rank-bw update: 2 N^3 (1 - bw/N) of the 2 N^3).  For a SINGLE matrix the time-dominant kernel
-        # is the latency-bound panel kernel (one workgroup, one barrier per pivot step): no roofline
-        # applies to it; its share is reported here.
         tot_ms = sum(v[0] for v in prof.values()) or 1.0
         time_dominant = max(prof.items(), key=lambda kv: kv[1][0])
-        breakdown["_time_dominant"] = {"class": time_dominant[0], "share_of_kernel_time": time_dominant[1][0] / tot_ms}
+        dominant = {"class": time_dominant[0], "share_of_kernel_time": time_dominant[1][0] / tot_ms,
+                    "ms_per_step": time_dominant[1][0] / args.steps,
+                    "bound": ("latency chain: one workgroup per matrix, one barrier per pivot step -- no roofline applies"
+                              if time_dominant[0] == "panel" else "see roofline")}
+        traffic, traffic_src = pmc_traffic(algo_name, n, batch, bw)
         if algo_id == g.ALGO_BLOCKED:
             ms, cnt = prof["update_rank_bw"]
-            _, bw = inv.resolved_blocking(n, batch)
             # ALGORITHMIC flops of one rank-bw update launch: 2 * N * (N - bw) * bw per matrix
             # (sum over the N/bw launches = 2 N^3 (1 - bw/N): the block's own columns are done in-panel)
             flops = 2.0 * n * max(n - bw, 0) * bw * batch
             avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
             ach = flops / avg_s / 1e12 if cnt else None
-            # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, x1024),
-            # collected offline with rocprofv3 --pmc (separate passes) on this exact config
-            traffic = None
-            pmc_path = os.path.join(ROOT, "profiles", "round1", "pmc_rank_bw2_n4096.json")
-            if n == 4096 and batch == 1 and bw == 256 and os.path.exists(pmc_path):
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch_corrected")
             roof = {"bound": "mfma", "kernel": "gj_rank_bw2_kernel", "achieved": ach,
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
-                    "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt / args.steps,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt / args.steps,
                     "algorithmic_flops_per_launch": flops,
-                    "share_of_step_time": (ms / args.steps) / (1e3 * instrumented / args.steps)}
+                    "algorithmic_bytes_per_launch": 8.0 * n * max(n - bw, 0) * batch + 8.0 * n * bw * batch,
+                    "share_of_step_time": (ms / args.steps) / (1e3 * instrumented / args.steps),
+                    "time_dominant": dominant}
         else:
             ms, cnt = prof["sweep_step"]
             bytes_per_launch = 8.0 * n * (n + 1) * batch  # one fp32 read + write of N rows x (N+1) live columns
             avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
             ach = bytes_per_launch / avg_s / 1e9 if cnt else None
             roof = {"bound": "hbm", "kernel": "gj_sweep_step_kernel", "achieved": ach, "peak": PEAK_HBM_GBPS,
-                    "unit": "GB/s", "frac": (ach / PEAK_HBM_GBPS) if ach else None, "traffic": None,
+                    "unit": "GB/s", "frac": (ach / PEAK_HBM_GBPS) if ach else None,
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": avg_s * 1e6, "launches_per_step": cnt / args.steps,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "share_of_step_time": (ms / args.steps) / (1e3 * instrumented / args.steps)}
+                    "share_of_step_time": (ms / args.steps) / (1e3 * instrumented / args.steps),
+                    "time_dominant": dominant,
+                    "note": ("two working copies of %.0f MiB: %s the 256 MiB Infinity Cache"
+                             % (n * n * 4 / 2 ** 20, "inside" if 2 * n * n * 4 <= 256 * 2 ** 20 else "beyond"))}
+
+    # T_e2e through the host-pointer drop-in (rank 0 only; pageable host memory both ways)
+    e2e = None
+    if rank == 0:
+        reps = 5 if n <= 4096 else 2
+        times, computes = [], []
+        flat = host.reshape(batch, -1)
+        for i in range(reps + 1):
+            te = time.perf_counter()
+            if batch == 1:
+                x = g.matrix_inv_32(flat[0], n)
+            else:
+                x, _ = g.matrix_inv_32_batched(host)
+            dt = time.perf_counter() - te
+            if i > 0:  # the first call creates the default context and its staging buffers
+                times.append(dt)
+                computes.append(g.last_timing()[1])
+        e2e = {"e2e_ms": 1e3 * statistics.median(times), "compute_ms_inside": 1e3 * statistics.median(computes),
+               "entry_point": "matrix_inv_32(vec, N)" if batch == 1 else "mi32_matrix_inv_32_batched",
+               "matrices_per_s_e2e": batch / statistics.median(times),
+               "what": "host vector in, host vector out (H2D + compute + D2H + status), median of %d calls; the reference's "
+                       "'Tempo Totale Impiegato' / 'Tempo Computazione' pair (mat_inv_32.cpp:385-386)" % reps}
+        del x
 
     total_matrices = world * batch * args.steps
     value = total_matrices / elapsed
@@ -261,15 +402,23 @@ def main():
         },
         "residual_inf": res_right,
         "residual_inf_left": res_left,
+        "frobenius_metric_abs": res_frob,
         "status_max": st_max,
         "roofline": roof,
         "kernel_breakdown": breakdown,
+        "e2e": e2e,
     }
+    if distribution is not None:
+        line["distribution"] = distribution
     if rank == 0 and not args.no_cpu_baseline:
         cb = cpu_baseline(host[0])
         line["cpu_baseline"] = cb
         line["cpu_baseline_oracle_port"] = oracle_port_baseline()
         line["speedup_vs_numpy_per_gpu"] = (value / world) / cb["value"] if cb.get("value") else None
+        if e2e:
+            line["speedup_vs_numpy_e2e"] = e2e["matrices_per_s_e2e"] / cb["value"]  # NumPy: one matrix per call
+        if n <= 8192:
+            line["residuals_reference_distributions"] = reference_distribution_residuals(inv, n, torch, dev)
     inv.close()
     if world > 1:
         dist.barrier()

@@ -15,18 +15,21 @@ from ._lib import (  # noqa: F401
     Mi32Error,
     build_library,
 )
-from .api import Inverter, just_inv, last_timing, matrix_inv_32, matrix_inv_32_batched, matrix_inv_64  # noqa: F401
-from .sharding import invert_sharded, shard_range  # noqa: F401
+from .api import Inverter, fp32_bench, just_inv, last_timing, matrix_inv_32, matrix_inv_32_batched, matrix_inv_64, matrix_inversion_no_pivots  # noqa: F401
+from .sharding import invert_distributed, invert_sharded, shard_range  # noqa: F401
 
 __all__ = [
     "matrix_inv_32",
     "matrix_inv_32_batched",
     "matrix_inv_64",
+    "matrix_inversion_no_pivots",
     "just_inv",
+    "fp32_bench",
     "last_timing",
     "Inverter",
     "shard_range",
     "invert_sharded",
+    "invert_distributed",
     "build_library",
     "Mi32Error",
 ]

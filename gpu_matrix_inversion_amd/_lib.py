@@ -43,8 +43,11 @@ C_ABI_SYMBOLS = (
     "mi32_set_profiling",
     "mi32_get_profile",
     "mi32_last_timing",
+    "mi32_bench_32",
     "mi32_resolve_algo",
     "mi32_matrix_inv_64",
+    "mi32_matrix_inversion_no_pivots",
+    "mi32_set_pivoting",
     "mi32_inv_device_f64",
     "mi32_resolve_blocking",
     "mi32_resolve_panel_widths",
@@ -56,6 +59,11 @@ C_ABI_SYMBOLS = (
 CXX_DROPIN_SYMBOL = "_Z13matrix_inv_32St6vectorIfSaIfEEi"
 # the fp64 twin of include/mat_inv_64.h: matrix_inversion_FP64(std::vector<double>, int)
 CXX_FP64_SYMBOL = "_Z21matrix_inversion_FP64St6vectorIdSaIdEEi"
+# the no-pivot variant of include/mat_inv_64.h: matrix_inversion_no_pivots(std::vector<double>, int)
+CXX_NOPIVOT_SYMBOL = "_Z26matrix_inversion_no_pivotsSt6vectorIdSaIdEEi"
+# the benchmark twin of include/mat_inv_bench.h: Res FP32_bench(std::vector<float>, int)
+CXX_BENCH_SYMBOL = "_Z10FP32_benchSt6vectorIfSaIfEEi"
+TIMES10_SLOTS = ("queue", "buffers", "build", "makeAug", "pivot", "row", "column", "compute", "getInverted", "total")
 
 
 class Mi32Error(RuntimeError):
@@ -124,6 +132,8 @@ def load() -> ctypes.CDLL:
     lib.mi32_set_profiling.argtypes = [vp, ctypes.c_int]
     lib.mi32_get_profile.restype = ctypes.c_int
     lib.mi32_get_profile.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
+    lib.mi32_bench_32.restype = ctypes.c_int
+    lib.mi32_bench_32.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ctypes.POINTER(ctypes.c_double)]
     lib.mi32_last_timing.restype = ctypes.c_int
     lib.mi32_last_timing.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     lib.mi32_resolve_algo.restype = ctypes.c_int
@@ -133,6 +143,10 @@ def load() -> ctypes.CDLL:
     dp = ctypes.POINTER(ctypes.c_double)
     lib.mi32_matrix_inv_64.restype = ctypes.c_int
     lib.mi32_matrix_inv_64.argtypes = [dp, ctypes.c_size_t, ctypes.c_int, dp]
+    lib.mi32_matrix_inversion_no_pivots.restype = ctypes.c_int
+    lib.mi32_matrix_inversion_no_pivots.argtypes = [dp, ctypes.c_size_t, ctypes.c_int, dp]
+    lib.mi32_set_pivoting.restype = ctypes.c_int
+    lib.mi32_set_pivoting.argtypes = [vp, ctypes.c_int]
     lib.mi32_inv_device_f64.restype = ctypes.c_int
     lib.mi32_inv_device_f64.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
     lib.mi32_resolve_panel_widths.restype = ctypes.c_int

@@ -76,6 +76,27 @@ def matrix_inv_64(matrix_vector, matrix_order: int) -> np.ndarray:
     return np.empty(0, dtype=np.float64)
 
 
+def matrix_inversion_no_pivots(matrix_vector, matrix_order: int) -> np.ndarray:
+    """Drop-in for the reference's ``matrix_inversion_no_pivots(std::vector<double>, int)`` (headers.h:11,
+    matrix_inversion_no_pivots.cpp:10): Gauss-Jordan in double with the diagonal entry as every step's pivot --
+    for diagonally dominant inputs.  Empty array for a bad shape or when a zero diagonal entry is met."""
+    lib = _lib.load()
+    n = int(matrix_order)
+    v = np.ascontiguousarray(np.asarray(matrix_vector, dtype=np.float64).reshape(-1))
+    if n <= 0 or int(v.size // n) != n:
+        return np.empty(0, dtype=np.float64)
+    out = np.empty(n * n, dtype=np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib.mi32_matrix_inversion_no_pivots(v.ctypes.data_as(dp), v.size, n, out.ctypes.data_as(dp))
+    if rc == MI32_OK:
+        return out
+    if rc == MI32_SINGULAR:
+        return out if os.environ.get("MI32_SINGULAR_KEEP", "0") not in ("", "0") else np.empty(0, dtype=np.float64)
+    if rc == _lib.MI32_RUNTIME_ERROR:
+        raise Mi32Error(lib.mi32_last_error().decode())
+    return np.empty(0, dtype=np.float64)
+
+
 def matrix_inv_32_batched(a: np.ndarray):
     """Host batch (B, N, N) -> (inverses (B, N, N), status int32[B])."""
     lib = _lib.load()
@@ -91,6 +112,27 @@ def matrix_inv_32_batched(a: np.ndarray):
     if rc == _lib.MI32_RUNTIME_ERROR:
         raise Mi32Error(lib.mi32_last_error().decode())
     return out, st
+
+
+def fp32_bench(matrix_vector, matrix_order: int):
+    """The reference's ``Res FP32_bench(vector<float>, int)`` (FP32_bench.cpp:11): returns ``(inverse, times)``
+    with ``times`` the ten durations of FP32_bench.cpp:256-443 in seconds, keyed by ``_lib.TIMES10_SLOTS``
+    (queue, buffers, build, makeAug, pivot, row, column, compute, getInverted, total); ``(empty, {})`` where the
+    reference returns an empty Res."""
+    lib = _lib.load()
+    n = int(matrix_order)
+    v = np.ascontiguousarray(np.asarray(matrix_vector, dtype=np.float32).reshape(-1))
+    if n <= 0 or int(v.size // n) != n:
+        return np.empty(0, dtype=np.float32), {}
+    out = np.empty(n * n, dtype=np.float32)
+    times = (ctypes.c_double * 10)()
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = lib.mi32_bench_32(v.ctypes.data_as(fp), v.size, n, out.ctypes.data_as(fp), times)
+    if rc == _lib.MI32_RUNTIME_ERROR:
+        raise Mi32Error(lib.mi32_last_error().decode())
+    if rc != MI32_OK:
+        return np.empty(0, dtype=np.float32), {}
+    return out, dict(zip(_lib.TIMES10_SLOTS, (float(t) for t in times)))
 
 
 def last_timing():
@@ -119,7 +161,7 @@ def just_inv(K: int, seed=None, inv=None):
 class Inverter:
     """Device-resident inversion of torch CUDA(HIP) tensors through the C ABI handle."""
 
-    def __init__(self, device=None, algo="auto", panel_width: int = 0, block_width: int = 0):
+    def __init__(self, device=None, algo="auto", panel_width: int = 0, block_width: int = 0, pivoting: bool = True):
         import torch
 
         self._torch = torch
@@ -135,6 +177,8 @@ class Inverter:
         _lib.check(self._lib.mi32_set_algo(self._h, self.algo), "mi32_set_algo")
         if panel_width or block_width:
             _lib.check(self._lib.mi32_set_blocking(self._h, panel_width, block_width), "mi32_set_blocking")
+        if not pivoting:  # the reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10), sweep path
+            _lib.check(self._lib.mi32_set_pivoting(self._h, 0), "mi32_set_pivoting")
 
     def close(self):
         if getattr(self, "_h", None):

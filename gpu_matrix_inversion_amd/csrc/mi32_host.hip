@@ -18,6 +18,7 @@
 
 #include "mat_inv_32.h"
 #include "mat_inv_64.h"
+#include "mat_inv_bench.h"
 #include "mi32_internal.h"
 
 using namespace mi32;
@@ -86,6 +87,7 @@ struct mi32_context {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     int algo = MI32_ALGO_AUTO;
+    bool pivoting = true;  // false: the reference's no-pivot variant (sweep kernels, the diagonal entry is the pivot)
     int panel_w = 0;
     int block_w = 0;
     // staging for the host-pointer entry points
@@ -124,6 +126,7 @@ static int env_int(const char *name, int dflt)
 
 static int resolve_algo(const mi32_context *h, int n)
 {
+    if (h && !h->pivoting) return MI32_ALGO_SWEEP;  // the no-pivot variant exists on the sweep path only
     int algo = h ? h->algo : MI32_ALGO_AUTO;
     if (algo == MI32_ALGO_AUTO) algo = env_int("MI32_ALGO", MI32_ALGO_AUTO);
     if (algo != MI32_ALGO_SWEEP && algo != MI32_ALGO_BLOCKED) algo = (n >= 32) ? MI32_ALGO_BLOCKED : MI32_ALGO_SWEEP;  // measured cross-over on MI355X
@@ -306,6 +309,14 @@ int mi32_set_algo(mi32_handle_t h, int algo)
     return MI32_OK;
 }
 
+int mi32_set_pivoting(mi32_handle_t h, int enable)
+{
+    if (!h) return MI32_BAD_SHAPE;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->pivoting = enable != 0;
+    return MI32_OK;
+}
+
 int mi32_set_lookahead(mi32_handle_t h, int enable)
 {
     if (!h) return MI32_BAD_SHAPE;
@@ -386,7 +397,7 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
     if (rc != MI32_OK) return rc;
     hipError_t e;
     if (algo == MI32_ALGO_SWEEP)
-        e = sweep_invert(make_sweep_plan(n), d_a, d_inv, batch, d_status, h->ws, h->stream, h->prof);
+        e = sweep_invert(make_sweep_plan(n), d_a, d_inv, batch, d_status, h->ws, h->stream, h->prof, h->pivoting);
     else {
         BlockedExec ex;
         ex.stream = h->stream;
@@ -431,7 +442,7 @@ int mi32_inv_device_f64(mi32_handle_t h, const double *d_a, int n, int batch, do
     if (rc != MI32_OK) return rc;
     rc = status_buffer(h, d_status, batch, &d_status);
     if (rc != MI32_OK) return rc;
-    hipError_t e = sweep_invert_f64(p, d_a, d_inv, batch, d_status, h->ws, h->stream, h->prof);
+    hipError_t e = sweep_invert_f64(p, d_a, d_inv, batch, d_status, h->ws, h->stream, h->prof, h->pivoting);
     if (e != hipSuccess) return fail(e, "kernel launch");
     return MI32_OK;
 }
@@ -511,11 +522,16 @@ static int ensure_io(mi32_context *h, size_t floats, size_t ints)
     return MI32_OK;
 }
 
-int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int *status)
+// The host-pointer path.  times10 (may be NULL): the reference's timing vector, FP32_bench.cpp:256-443 /
+// res_struct.h:4-6 -- [0] queue/context, [1] buffers (+ the H2D copy the reference's CL_MEM_COPY_HOST_PTR does),
+// [2] program build, [3] makeAugmented, [4] pivot, [5] row, [6] column, [7] compute, [8] getInverted (+ D2H),
+// [9] total; seconds.  The per-phase slots come from HIP events on the launch stream (mi32_set_profiling).
+static int host_invert_32(const float *a, int n, int batch, float *inv, int *status, double *times10)
 {
     if (!a || !inv || n <= 0 || batch <= 0) return MI32_BAD_SHAPE;
+    const auto tq0 = std::chrono::steady_clock::now();
     mi32_context *h = nullptr;
-    int rc = default_context(&h);
+    int rc = default_context(&h);  // the reference's platform / device / context / queue bring-up (cached here)
     if (rc != MI32_OK) return rc;
     std::lock_guard<std::mutex> lk(g_host_call_mu);  // one host-pointer call at a time: the staging buffers are shared
     const auto t0 = std::chrono::steady_clock::now();
@@ -523,6 +539,14 @@ int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int
     const size_t floats = (size_t)batch * n * n;
     rc = ensure_io(h, floats, (size_t)batch);
     if (rc != MI32_OK) return rc;
+    if (times10) {
+        rc = mi32_reserve(h, n, batch);  // workspace allocation belongs to the "buffers" slot
+        if (rc != MI32_OK) return rc;
+        rc = mi32_set_profiling(h, 1);
+        if (rc != MI32_OK) return rc;
+        double ms[KC_COUNT]; long long cnt[KC_COUNT];
+        (void)mi32_get_profile(h, ms, cnt, KC_COUNT);  // drop what an earlier call left
+    }
     MI32_HIP(hipMemcpyAsync(h->d_in, a, floats * sizeof(float), hipMemcpyHostToDevice, h->stream));
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t1 = std::chrono::steady_clock::now();
@@ -537,6 +561,25 @@ int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int
     const auto t3 = std::chrono::steady_clock::now();
     g_last_total = std::chrono::duration<double>(t3 - t0).count();
     g_last_compute = std::chrono::duration<double>(t2 - t1).count();
+    if (times10) {
+        double ms[KC_COUNT]; long long cnt[KC_COUNT];
+        rc = mi32_get_profile(h, ms, cnt, KC_COUNT);
+        (void)mi32_set_profiling(h, 0);
+        if (rc != MI32_OK) return rc;
+        times10[0] = std::chrono::duration<double>(t0 - tq0).count();
+        times10[1] = std::chrono::duration<double>(t1 - t0).count();
+        times10[2] = 0.0;  // one ahead-of-time compiled code object: nothing is built at run time
+        times10[3] = ms[KC_INIT] * 1e-3;
+        // the panel kernel IS maxPivot + finalMaxPivot + pivotElements + fixRow (+ fixColumn on the panel's own
+        // columns); the sweep path's one fused launch per step is accounted to the column slot, where the
+        // reference spends its time (fixColumnKernel)
+        times10[4] = ms[KC_PANEL] * 1e-3;
+        times10[5] = 0.0;  // fixRow has no launch of its own
+        times10[6] = (ms[KC_SWEEP_STEP] + ms[KC_UPDATE_IN] + ms[KC_UPDATE_OUT] + ms[KC_TRANSPOSE]) * 1e-3;
+        times10[7] = g_last_compute;
+        times10[8] = ms[KC_FINISH] * 1e-3 + std::chrono::duration<double>(t3 - t2).count();
+        times10[9] = std::chrono::duration<double>(t3 - tq0).count();
+    }
     int worst = MI32_OK;
     for (int b = 0; b < batch; ++b) {
         if (status) status[b] = st[(size_t)b];
@@ -554,6 +597,18 @@ int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int
     return worst;
 }
 
+int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int *status)
+{
+    return host_invert_32(a, n, batch, inv, status, nullptr);
+}
+
+int mi32_bench_32(const float *a_rowmajor, size_t a_len, int n, float *inv_rowmajor, double *times10)
+{
+    if (n <= 0 || !times10) return MI32_BAD_SHAPE;
+    if ((int)(a_len / (size_t)n) != n) return MI32_BAD_SHAPE;
+    return host_invert_32(a_rowmajor, n, 1, inv_rowmajor, nullptr, times10);
+}
+
 int mi32_matrix_inv_32(const float *a_rowmajor, size_t a_len, int n, float *inv_rowmajor)
 {
     // the reference's guards, mat_inv_32.cpp:206-215 (integer division included)
@@ -562,7 +617,19 @@ int mi32_matrix_inv_32(const float *a_rowmajor, size_t a_len, int n, float *inv_
     return mi32_matrix_inv_32_batched(a_rowmajor, n, 1, inv_rowmajor, nullptr);
 }
 
+static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor, bool pivoting);
+
 int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor)
+{
+    return host_invert_64(a_rowmajor, a_len, n, inv_rowmajor, true);
+}
+
+int mi32_matrix_inversion_no_pivots(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor)
+{
+    return host_invert_64(a_rowmajor, a_len, n, inv_rowmajor, false);
+}
+
+static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor, bool pivoting)
 {
     // the guards of the fp32 library (mat_inv_32.cpp:206-215); matrix_inversion_FP64.cpp has the same two
     if (n <= 0) return MI32_BAD_SHAPE;
@@ -581,7 +648,12 @@ int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *in
     MI32_HIP(hipMemcpyAsync(din, a_rowmajor, elems * sizeof(double), hipMemcpyHostToDevice, h->stream));
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t1 = std::chrono::steady_clock::now();
-    rc = mi32_inv_device_f64(h, din, n, 1, dout, h->d_status);
+    {
+        const bool saved = h->pivoting;  // the default context is only ever used under g_host_call_mu
+        h->pivoting = pivoting;
+        rc = mi32_inv_device_f64(h, din, n, 1, dout, h->d_status);
+        h->pivoting = saved;
+    }
     if (rc != MI32_OK) return rc;
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t2 = std::chrono::steady_clock::now();
@@ -619,6 +691,35 @@ std::vector<float> matrix_inv_32(std::vector<float> matrix_vector, int matrix_or
     if (rc == MI32_SINGULAR && env_int("MI32_SINGULAR_KEEP", 0)) return result;
     if (rc == MI32_RUNTIME_ERROR) std::fprintf(stderr, "matrix_inv_32: %s\n", mi32_last_error());
     return {};
+}
+
+// ---- the reference's no-pivot variant, unchanged signature (matrix_inversion/headers.h:11) ----
+std::vector<double> matrix_inversion_no_pivots(std::vector<double> matrix_vector, int matrix_order)
+{
+    if (matrix_order <= 0) return {};
+    if ((int)(matrix_vector.size() / (size_t)matrix_order) != matrix_order) return {};
+    std::vector<double> result((size_t)matrix_order * matrix_order, 0.0);
+    const int rc = mi32_matrix_inversion_no_pivots(matrix_vector.data(), matrix_vector.size(), matrix_order, result.data());
+    if (rc == MI32_OK) return result;
+    // a zero diagonal entry on the way: {} like the reference (exact-identity check, matrix_inversion_no_pivots.cpp:670)
+    if (rc == MI32_SINGULAR && env_int("MI32_SINGULAR_KEEP", 0)) return result;
+    if (rc == MI32_RUNTIME_ERROR) std::fprintf(stderr, "matrix_inversion_no_pivots: %s\n", mi32_last_error());
+    return {};
+}
+
+// ---- the reference's benchmark twin, unchanged signature (matrix_inversion/headers.h:15, FP32_bench.cpp:11) ----
+Res FP32_bench(std::vector<float> matrix_vector, int matrix_order)
+{
+    Res res;
+    if (matrix_order <= 0) return res;                                                       // FP32_bench.cpp:212
+    if ((int)(matrix_vector.size() / (size_t)matrix_order) != matrix_order) return res;      // :217
+    std::vector<float> inv((size_t)matrix_order * matrix_order, 0.0f);
+    std::vector<double> times(10, 0.0);
+    const int rc = mi32_bench_32(matrix_vector.data(), matrix_vector.size(), matrix_order, inv.data(), times.data());
+    if (rc != MI32_OK) return res;   // {} like the reference's error paths (:456)
+    res.inversa32 = std::move(inv);
+    res.times = std::move(times);
+    return res;
 }
 
 // ---- the reference's fp64 entry point, unchanged signature (matrix_inversion/headers.h:9) ----

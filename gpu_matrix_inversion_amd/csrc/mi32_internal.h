@@ -96,11 +96,12 @@ size_t blocked_workspace_bytes(const BlockedPlan &p, int batch);
 
 // Enqueue a whole inversion on `stream`.  ws: workspace of at least the size
 // reported above, 256-byte aligned.
+// pivoting = false: the reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10), the diagonal entry is the pivot
 hipError_t sweep_invert(const SweepPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *ws,
-                        hipStream_t stream, Profiler *prof);
+                        hipStream_t stream, Profiler *prof, bool pivoting = true);
 // the fp64 twin (matrix_inversion_FP64 of the reference): same launches on doubles
 hipError_t sweep_invert_f64(const SweepPlan &p, const double *d_a, double *d_inv, int batch, int *d_status, void *ws,
-                            hipStream_t stream, Profiler *prof);
+                            hipStream_t stream, Profiler *prof, bool pivoting = true);
 // streams/events a blocked inversion is enqueued with: `aux` (may be null) carries the look-ahead half
 // of each rank-bw update; events[0 .. n/2) mark "second-stream work done", events[n/2 .. n) "panel phase done"
 struct BlockedExec {

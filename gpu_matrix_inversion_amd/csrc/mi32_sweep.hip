@@ -206,7 +206,9 @@ __device__ __forceinline__ void set_comp(Vec4<T> &v, int c, T x)
     else v.w = x;
 }
 
-template <typename T, int TR>
+// PIVOT = false: the reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10): the pivot of step r is the
+// diagonal entry (findCrr, :41-45) -- no arg-max records are read or written, no row is swapped.
+template <typename T, int TR, bool PIVOT>
 __global__ __launch_bounds__(kSweepThreads) void gj_sweep_step_kernel(const T *__restrict__ src_all,
                                                                        T *__restrict__ dst_all, int n, int ld,
                                                                        size_t wstride, int r,
@@ -222,20 +224,23 @@ __global__ __launch_bounds__(kSweepThreads) void gj_sweep_step_kernel(const T *_
     T *dst = dst_all + (size_t)b * wstride;
 
     // 1. finalMaxPivot: reduce the per-row-tile records of column r
-    PivotRec<T> k = PivotRec<T>::none();
-    for (int t = tid; t < npart; t += kSweepThreads) {
-        const PivotRec<T> o = keys_in[(size_t)b * npart + t];
-        k = o.beats(k) ? o : k;
+    int p = r;
+    if constexpr (PIVOT) {
+        PivotRec<T> k = PivotRec<T>::none();
+        for (int t = tid; t < npart; t += kSweepThreads) {
+            const PivotRec<T> o = keys_in[(size_t)b * npart + t];
+            k = o.beats(k) ? o : k;
+        }
+        k = wave_max_rec<T>(k);
+        if ((tid & 63) == 0) s_key[tid >> 6] = k;
+        __syncthreads();
+        {
+            const PivotRec<T> a = s_key[0].beats(s_key[1]) ? s_key[0] : s_key[1];
+            const PivotRec<T> c = s_key[2].beats(s_key[3]) ? s_key[2] : s_key[3];
+            k = a.beats(c) ? a : c;
+        }
+        p = k.row(r);
     }
-    k = wave_max_rec<T>(k);
-    if ((tid & 63) == 0) s_key[tid >> 6] = k;
-    __syncthreads();
-    {
-        const PivotRec<T> a = s_key[0].beats(s_key[1]) ? s_key[0] : s_key[1];
-        const PivotRec<T> c = s_key[2].beats(s_key[3]) ? s_key[2] : s_key[3];
-        k = a.beats(c) ? a : c;
-    }
-    const int p = k.row(r);
     const T piv = src[(size_t)p * ld + r];  // read before the swap, as mat_inv_32.cpp:70,129-130
 
     const int j4 = (blockIdx.x * kSweepThreads + tid) * 4;
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(kSweepThreads) void gj_sweep_step_kernel(const T *_
     const int rc = r - j4;                   // component of column r inside this thread's group, if 0..3
     const bool has_r = (rc >= 0 && rc < 4);
     const int nc = r + 1 - j4;               // component of column r+1
-    const bool has_next = (nc >= 0 && nc < 4) && (r + 1 < n);
+    const bool has_next = PIVOT && (nc >= 0 && nc < 4) && (r + 1 < n);
     const int row0 = blockIdx.y * TR;
 
     // 2. fixRow: the normalised pivot row slice (IEEE division), identity entry -> 1/piv
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256) void unpermute_columns_kernel(const T *__restr
 
 template <typename T, int TR>
 static hipError_t sweep_run(const SweepPlan &p, const T *d_a, T *d_inv, int batch, int *d_status, const SweepWs &ws,
-                            hipStream_t stream, Profiler *prof)
+                            hipStream_t stream, Profiler *prof, bool pivoting)
 {
     const dim3 grid(p.col_tiles, p.row_tiles, batch);
     const dim3 block(kSweepThreads);
@@ -354,8 +359,12 @@ static hipError_t sweep_run(const SweepPlan &p, const T *d_a, T *d_inv, int batc
     for (int r = 0; r < p.n; ++r) {
         const bool even = (r % 2) == 0;
         ProfScope ps(prof, KC_SWEEP_STEP, stream);
-        hipLaunchKernelGGL((gj_sweep_step_kernel<T, TR>), grid, block, 0, stream, even ? w0 : w1, even ? w1 : w0, p.n,
-                           p.ld, ws.wstride, r, even ? k0 : k1, even ? k1 : k0, p.row_tiles, ws.orig, d_status);
+        if (pivoting)
+            hipLaunchKernelGGL((gj_sweep_step_kernel<T, TR, true>), grid, block, 0, stream, even ? w0 : w1, even ? w1 : w0,
+                               p.n, p.ld, ws.wstride, r, even ? k0 : k1, even ? k1 : k0, p.row_tiles, ws.orig, d_status);
+        else
+            hipLaunchKernelGGL((gj_sweep_step_kernel<T, TR, false>), grid, block, 0, stream, even ? w0 : w1, even ? w1 : w0,
+                               p.n, p.ld, ws.wstride, r, even ? k0 : k1, even ? k1 : k0, p.row_tiles, ws.orig, d_status);
     }
     const T *fin = (p.n % 2 == 0) ? w0 : w1;  // the last-written copy (mat_inv_32.cpp:369-372)
     ProfScope ps(prof, KC_FINISH, stream);
@@ -368,27 +377,27 @@ static hipError_t sweep_run(const SweepPlan &p, const T *d_a, T *d_inv, int batc
 
 template <typename T>
 static hipError_t sweep_invert_t(const SweepPlan &p, const T *d_a, T *d_inv, int batch, int *d_status, void *wsp,
-                                 hipStream_t stream, Profiler *prof)
+                                 hipStream_t stream, Profiler *prof, bool pivoting)
 {
     SweepWs ws;
     sweep_carve(p, batch, wsp, &ws, sizeof(T));
     switch (p.tr) {
-        case 4: return sweep_run<T, 4>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
-        case 8: return sweep_run<T, 8>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
-        case 16: return sweep_run<T, 16>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
-        default: return sweep_run<T, 32>(p, d_a, d_inv, batch, d_status, ws, stream, prof);
+        case 4: return sweep_run<T, 4>(p, d_a, d_inv, batch, d_status, ws, stream, prof, pivoting);
+        case 8: return sweep_run<T, 8>(p, d_a, d_inv, batch, d_status, ws, stream, prof, pivoting);
+        case 16: return sweep_run<T, 16>(p, d_a, d_inv, batch, d_status, ws, stream, prof, pivoting);
+        default: return sweep_run<T, 32>(p, d_a, d_inv, batch, d_status, ws, stream, prof, pivoting);
     }
 }
 
 hipError_t sweep_invert(const SweepPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *wsp,
-                        hipStream_t stream, Profiler *prof)
+                        hipStream_t stream, Profiler *prof, bool pivoting)
 {
-    return sweep_invert_t<float>(p, d_a, d_inv, batch, d_status, wsp, stream, prof);
+    return sweep_invert_t<float>(p, d_a, d_inv, batch, d_status, wsp, stream, prof, pivoting);
 }
 hipError_t sweep_invert_f64(const SweepPlan &p, const double *d_a, double *d_inv, int batch, int *d_status, void *wsp,
-                            hipStream_t stream, Profiler *prof)
+                            hipStream_t stream, Profiler *prof, bool pivoting)
 {
-    return sweep_invert_t<double>(p, d_a, d_inv, batch, d_status, wsp, stream, prof);
+    return sweep_invert_t<double>(p, d_a, d_inv, batch, d_status, wsp, stream, prof, pivoting);
 }
 
 }  // namespace mi32

@@ -92,6 +92,12 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
  * 16 N (N+1) bytes per step); bit-identical to the oracle's fp64 restatement.  Host-pointer twin of the C++
  * function in mat_inv_64.h, and the device-resident batched form (asynchronous on the context's stream). */
 int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor);
+/* The reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10, headers.h:11): the same steps with the
+ * diagonal entry as pivot, no search and no swap -- for diagonally dominant inputs.  Host-pointer twin in double
+ * (as the reference ships it); mi32_set_pivoting(h, 0) selects it for the device-resident calls of a context, in
+ * either precision (it runs on the sweep path).  A zero / non-finite diagonal entry -> MI32_SINGULAR. */
+int mi32_matrix_inversion_no_pivots(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor);
+int mi32_set_pivoting(mi32_handle_t h, int enable);
 int mi32_inv_device_f64(mi32_handle_t h, const double *d_a, int n, int batch, double *d_inv, int *d_status);
 
 /* Device-side verification (the reference's matrix_multiply.cpp:17-36,193-200 and
@@ -110,6 +116,18 @@ int mi32_residual_device(mi32_handle_t h, const float *d_a, const float *d_x, in
 #define MI32_KC_COUNT 7
 int mi32_set_profiling(mi32_handle_t h, int enable);
 int mi32_get_profile(mi32_handle_t h, double *ms_per_class, long long *launches_per_class, int nclasses);
+
+/* The reference's benchmark twin (Res FP32_bench(vector<float>, int), FP32_bench.cpp:11; C++ signature in
+ * mat_inv_bench.h): one host-pointer inversion that also fills times10[10] with the reference's timing vector
+ * (FP32_bench.cpp:256-443), seconds:
+ *   [0] queue/context (the cached default context: ~0 after the first call)   [1] buffers: staging + workspace
+ *   allocation and the H2D copy (the reference's CL_MEM_COPY_HOST_PTR)        [2] program build: 0 (one AOT code
+ *   object)   [3] makeAugmented = init kernel   [4] pivot = the panel kernels (search + swap + normalise, and
+ *   the elimination of the panel's own columns)   [5] fixRow: 0, it has no launch of its own   [6] fixColumn =
+ *   in-block + rank-bw updates (+ panel transposes), or the fused step launches of the sweep path
+ *   [7] compute (wall time of the device-resident inversion)   [8] getInverted = un-permutation kernels + D2H
+ *   [9] total.  Slots 3-6 and the kernel part of 8 are HIP-event durations on the launch stream. */
+int mi32_bench_32(const float *a_rowmajor, size_t a_len, int n, float *inv_rowmajor, double *times10);
 
 /* ---- introspection -------------------------------------------------------- */
 /* The two durations the reference prints per call ("Tempo Totale Impiegato",

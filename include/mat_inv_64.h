@@ -14,3 +14,9 @@ inline std::vector<double> matrix_inv_64(std::vector<double> matrix_vector, int 
 {
     return matrix_inversion_FP64(static_cast<std::vector<double> &&>(matrix_vector), matrix_order);
 }
+
+// The reference's no-pivot variant (headers.h:11, body matrix_inversion_no_pivots.cpp:10): Gauss-Jordan in double
+// with the diagonal entry as the pivot of every step (findCrr / fixRow / copyCirColumn / fixColumn, kernels :13-70)
+// -- for diagonally dominant inputs.  Same call shape; an empty vector for a bad shape or when a zero / non-finite
+// diagonal entry is met (the reference returns {} when the reduced left half is not exactly I, :670).
+std::vector<double> matrix_inversion_no_pivots(std::vector<double> matrix_vector, int matrix_order);

@@ -250,8 +250,7 @@ int gjo_matrix_inv_32(const float *in, size_t in_len, int n, float *out, int piv
  * original index of the pivot row of step r).  Every skipped operation in
  * this form is one that the augmented form performs on an exact 0 or 1, so the
  * stored values are identical. */
-int gjo_matrix_inv_32_inplace(const float *in, size_t in_len, int n, float *out, int arith_mode,
-                              int *pivots)
+static int inv32_inplace_impl(const float *in, size_t in_len, int n, float *out, int arith_mode, int *pivots, int pivoting)
 {
     if (!shape_ok(in_len, n)) return GJO_BAD_SHAPE;
     const size_t ld = (size_t)n;
@@ -269,7 +268,7 @@ int gjo_matrix_inv_32_inplace(const float *in, size_t in_len, int n, float *out,
     int status = input_status_f32(in, n);
 
     for (int r = 0; r < n; ++r) {
-        const int p = max_pivot_true(m, ld, n, r);
+        const int p = pivoting ? max_pivot_true(m, ld, n, r) : r; /* no-pivot variant: the diagonal entry, findCrr */
         const float piv = m[(size_t)p * ld + r];
         if (pivots) pivots[r] = p;
         if (bad_pivot((double)piv)) status = GJO_SINGULAR;
@@ -310,7 +309,7 @@ int gjo_matrix_inv_32_inplace(const float *in, size_t in_len, int n, float *out,
  * fp32 library) is the same five-kernel step in double; here the in-place N x N form of it with true partial
  * pivoting (largest |a|, lowest row among equals), IEEE division and one fused multiply-add per element
  * (exact-zero multipliers skipped, matrix_inversion_FP64.cpp:28). */
-int gjo_matrix_inv_64_inplace(const double *in, size_t in_len, int n, double *out, int *pivots)
+static int inv64_inplace_impl(const double *in, size_t in_len, int n, double *out, int *pivots, int pivoting)
 {
     if (!shape_ok(in_len, n)) return GJO_BAD_SHAPE;
     const size_t ld = (size_t)n;
@@ -327,7 +326,7 @@ int gjo_matrix_inv_64_inplace(const double *in, size_t in_len, int n, double *ou
     for (int r = 0; r < n; ++r) {
         int p = r;
         double best = -1.0;
-        for (int i = r; i < n; ++i) {
+        for (int i = r; i < (pivoting ? n : r + 1); ++i) { /* no-pivot variant: the diagonal entry only */
             const double v = fabs(m[(size_t)i * ld + r]);
             if (v > best) { best = v; p = i; } /* NaN never wins, the first maximum is kept */
         }
@@ -358,6 +357,27 @@ int gjo_matrix_inv_64_inplace(const double *in, size_t in_len, int n, double *ou
         for (int c = 0; c < n; ++c) out[(size_t)i * n + orig[c]] = m[(size_t)i * ld + c];
     free(m); free(orig); free(rowr);
     return status;
+}
+
+int gjo_matrix_inv_32_inplace(const float *in, size_t in_len, int n, float *out, int arith_mode, int *pivots)
+{
+    return inv32_inplace_impl(in, in_len, n, out, arith_mode, pivots, 1);
+}
+int gjo_matrix_inv_64_inplace(const double *in, size_t in_len, int n, double *out, int *pivots)
+{
+    return inv64_inplace_impl(in, in_len, n, out, pivots, 1);
+}
+/* The reference's no-pivot variant, matrix_inversion_no_pivots.cpp:10 (kernels :13-70, loop :482-560): per step
+ * findCrr (the diagonal entry, no search, no swap), fixRow (IEEE division), copyCirColumn + fixColumn (skip zero
+ * multipliers, :29).  Same in-place form; a zero / non-finite diagonal entry -> GJO_SINGULAR (the reference
+ * returns {} when the reduced left half is not exactly I, :670). */
+int gjo_matrix_inv_64_nopivot(const double *in, size_t in_len, int n, double *out)
+{
+    return inv64_inplace_impl(in, in_len, n, out, NULL, 0);
+}
+int gjo_matrix_inv_32_nopivot(const float *in, size_t in_len, int n, float *out, int arith_mode)
+{
+    return inv32_inplace_impl(in, in_len, n, out, arith_mode, NULL, 0);
 }
 
 /* ---- blocked restatement (CPU mirror of the HIP blocked path) ---------- */

@@ -74,6 +74,11 @@ int gjo_matrix_inv_32_inplace(const float *in, size_t in_len, int n, float *out,
  * true partial pivoting and one fma per element. */
 int gjo_matrix_inv_64_inplace(const double *in, size_t in_len, int n, double *out, int *pivots);
 
+/* The reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10; headers.h:11): the pivot of step r is the
+ * diagonal entry; fp64 as the reference ships it, and the same steps in fp32. */
+int gjo_matrix_inv_64_nopivot(const double *in, size_t in_len, int n, double *out);
+int gjo_matrix_inv_32_nopivot(const float *in, size_t in_len, int n, float *out, int arith_mode);
+
 /* Blocked (rank-b delayed update) restatement of the same elimination: the
  * CPU mirror of the HIP blocked path's operation order (panel of width w
  * factored with partial pivoting, then one rank-w update of every other

@@ -73,6 +73,10 @@ def _load():
     dp = ctypes.POINTER(ctypes.c_double)
     lib.gjo_matrix_inv_64_inplace.restype = ctypes.c_int
     lib.gjo_matrix_inv_64_inplace.argtypes = [dp, ctypes.c_size_t, ctypes.c_int, dp, ip]
+    lib.gjo_matrix_inv_64_nopivot.restype = ctypes.c_int
+    lib.gjo_matrix_inv_64_nopivot.argtypes = [dp, ctypes.c_size_t, ctypes.c_int, dp]
+    lib.gjo_matrix_inv_32_nopivot.restype = ctypes.c_int
+    lib.gjo_matrix_inv_32_nopivot.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ctypes.c_int]
     lib.gjo_matrix_inv_32_blocked2w.restype = ctypes.c_int
     lib.gjo_matrix_inv_32_blocked2w.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ip, ctypes.c_int, ctypes.c_int, ip]
     for nm in ("gjo_residual_inf", "gjo_residual_inf_left", "gjo_frobenius_metric"):
@@ -166,6 +170,26 @@ def matrix_inv_32_blocked(vec, n: int, w: int = 16, return_info: bool = False):
     if return_info:
         return out, {"status": st, "pivots": piv}
     return out
+
+
+def matrix_inversion_no_pivots(vec, n: int, return_info: bool = False):
+    """The reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10): fp64 for a float64 input (as the
+    reference ships it), the same steps in fp32 for a float32 input.  Flat inverse, or an empty array on a shape error."""
+    lib = _load()
+    f64 = np.asarray(vec).dtype == np.float64
+    dt = np.float64 if f64 else np.float32
+    v = np.ascontiguousarray(np.asarray(vec, dtype=dt).reshape(-1))
+    n = int(n)
+    if n <= 0 or int(v.size // n) != n:
+        empty = np.empty(0, dtype=dt)
+        return (empty, {"status": STATUS_BAD_SHAPE}) if return_info else empty
+    out = np.empty(n * n, dtype=dt)
+    if f64:
+        dp = ctypes.POINTER(ctypes.c_double)
+        st = lib.gjo_matrix_inv_64_nopivot(v.ctypes.data_as(dp), v.size, n, out.ctypes.data_as(dp))
+    else:
+        st = lib.gjo_matrix_inv_32_nopivot(_fp(v), v.size, n, _fp(out), ARITH_FMA)
+    return (out, {"status": st}) if return_info else out
 
 
 def matrix_inv_32_blocked2(vec, n: int, w=16, bw: int = 256, return_info: bool = False):

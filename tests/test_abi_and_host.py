@@ -46,6 +46,18 @@ def test_every_declared_symbol_is_exported():
     assert getattr(lib, _lib.CXX_FP64_SYMBOL) is not None
     out = subprocess.run(["c++filt", _lib.CXX_FP64_SYMBOL], capture_output=True, text=True).stdout.strip()
     assert out == "matrix_inversion_FP64(std::vector<double, std::allocator<double> >, int)"
+    # std::vector<double> matrix_inversion_no_pivots(std::vector<double>, int) -- include/mat_inv_64.h (headers.h:11)
+    assert getattr(lib, _lib.CXX_NOPIVOT_SYMBOL) is not None
+    out = subprocess.run(["c++filt", _lib.CXX_NOPIVOT_SYMBOL], capture_output=True, text=True).stdout.strip()
+    assert out == "matrix_inversion_no_pivots(std::vector<double, std::allocator<double> >, int)"
+    # Res FP32_bench(std::vector<float>, int) -- include/mat_inv_bench.h (headers.h:15, res_struct.h:4-6)
+    assert getattr(lib, _lib.CXX_BENCH_SYMBOL) is not None
+    out = subprocess.run(["c++filt", _lib.CXX_BENCH_SYMBOL], capture_output=True, text=True).stdout.strip()
+    assert out == "FP32_bench(std::vector<float, std::allocator<float> >, int)"
+    hb = open(os.path.join(ROOT, "include", "mat_inv_bench.h")).read()
+    assert "Res FP32_bench(std::vector<float> matrix_vector, int matrix_order);" in hb
+    assert re.search(r"struct Res \{\s*std::vector<double> inversa64;\s*std::vector<double> times;\s*"
+                     r"std::vector<float> inversa32;\s*\};", hb)
 
 
 def test_dropin_header_matches_reference_declaration():
@@ -219,3 +231,57 @@ def test_status_codes_and_boundary_rule_are_documented():
     """include/mat_inv_32_c.h states the invalid-matrix rule the tests hold both paths to."""
     h = open(os.path.join(ROOT, "include", "mat_inv_32_c.h")).read()
     assert "non-finite entry" in h and "NaN-filled" in h
+
+
+_DIST_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import gpu_matrix_inversion_amd as g
+import oracle as O
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+rng = np.random.default_rng(5)
+B, n = 7, 24   # ragged over 3 ranks: 3 + 3 + 1; over 2: 4 + 3
+a = np.stack([(rng.uniform(-1, 1, (n, n)) + np.sqrt(n) * np.eye(n))[rng.permutation(n)] for _ in range(B)]).astype(np.float32)
+a[5] = 1.0      # one singular member: its status must reach root, the worst status every rank
+calls = []
+def oracle_fn(shard):   # the test injects the checker as the per-shard function; the product never does
+    calls.append(shard.shape[0])
+    res = [O.matrix_inv_32(m.numpy(), n, return_info=True) for m in shard]
+    return (torch.from_numpy(np.stack([r[0].reshape(n, n) for r in res])),
+            torch.tensor([r[1]["status"] for r in res], dtype=torch.int32))
+bufs = {{}}
+for rep in range(2):    # second call re-uses the buffers
+    inv, st, worst, tm = g.invert_distributed(torch.from_numpy(a) if rank == 0 else None, oracle_fn, root=0,
+                                              shard_buffers=bufs)
+    lo, hi = g.shard_range(B, world, rank)
+    assert calls[-1] == hi - lo                      # each rank inverts only its own shard
+    assert worst == 2                                 # all_reduce(MAX) of the status words
+    assert set(tm) == {{"scatter", "compute", "gather"}}
+    if rank == 0:
+        assert inv.shape == (B, n, n) and st.tolist() == [0, 0, 0, 0, 0, 2, 0]
+        full = np.stack([O.matrix_inv_32(a[b], n).reshape(n, n) for b in range(B)])
+        ok = [b for b in range(B) if b != 5]
+        assert np.array_equal(inv.numpy()[ok], full[ok])   # distributed result == unsharded result, bit for bit
+    else:
+        assert inv.shape == (hi - lo, n, n) and st.shape == (hi - lo,)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_batch_from_root_gloo(tmp_path, world):
+    """The xGMI distribution path on CPU ranks (gloo): the batch lives on rank 0 only, shards travel by grouped
+    point-to-point sends, results and status words come back the same way, the worst status is all-reduced."""
+    script = tmp_path / "dist_worker.py"
+    script.write_text(_DIST_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29540 + world), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o

@@ -11,6 +11,7 @@ Tolerances (fp32, stated once):
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -612,3 +613,106 @@ def test_device_call_without_status_buffer(inv_blocked):
                                           ctypes.c_void_p(out.data_ptr()), None)
     torch.cuda.synchronize()
     assert rc == 0 and torch.equal(out, want)
+
+
+def test_fp32_bench_twin_fills_the_references_ten_timing_slots(oracle, tmp_path):
+    """Res FP32_bench(vector<float>, int) (FP32_bench.cpp:11, res_struct.h:4-6): same inverse as matrix_inv_32 and
+    the reference's ten durations -- queue, buffers, build, makeAug, pivot, row, column, compute, getInverted,
+    total (FP32_bench.cpp:256-443) -- through Python and through a C++ caller of include/mat_inv_bench.h."""
+    n = 700
+    a = dist_matrix("ref100", n, 4)
+    want = g.matrix_inv_32(a.reshape(-1), n)
+    got, t = g.fp32_bench(a.reshape(-1), n)
+    assert np.array_equal(got, want)
+    assert list(t) == list(_lib.TIMES10_SLOTS) and all(v >= 0 for v in t.values())
+    assert t["build"] == 0.0 and t["row"] == 0.0                      # AOT code object; fixRow has no launch
+    assert t["makeAug"] > 0 and t["pivot"] > 0 and t["column"] > 0 and t["getInverted"] > 0
+    assert t["pivot"] + t["column"] + t["makeAug"] <= t["compute"] * 1.05
+    assert t["buffers"] + t["compute"] + t["getInverted"] <= t["total"] * 1.05
+    assert t["compute"] < t["total"] < 5.0
+    assert g.fp32_bench(a.reshape(-1), n + 1)[1] == {}                    # bad shape -> empty Res
+    assert g.fp32_bench(np.ones(64, np.float32), 8)[1] == {}             # invalid matrix -> empty Res
+    src = tmp_path / "bench_caller.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "mat_inv_bench.h"
+int main() {
+    std::vector<float> a = {2, 1, 0,  1, 3, 1,  0, 1, 4};
+    Res r = FP32_bench(a, 3);
+    std::printf("%zu %zu %zu\n", r.inversa32.size(), r.times.size(), r.inversa64.size());
+    for (float v : r.inversa32) std::printf("%.9g\n", v);
+    Res bad = FP32_bench(a, 2);
+    std::printf("bad %zu %zu\n", bad.inversa32.size(), bad.times.size());
+    return 0;
+}
+''')
+    exe = tmp_path / "bench_caller"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lmat_inv_32", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "9 10 0" and lines[-1] == "bad 0 0"
+    got3 = np.array([float(v) for v in lines[1:10]], np.float32)
+    assert np.allclose(got3, oracle.matrix_inv_32(np.array([2, 1, 0, 1, 3, 1, 0, 1, 4], np.float32), 3), rtol=1e-6)
+
+
+def test_sweep_series_line_format_and_error_magnitude(tmp_path):
+    """tools/sweep_series.py = the reference's size sweep (matrix_inv_pyopencl.py:358-371: N = 10, 20, ..., one line
+    `N t_compute t_total err` per size, err = sqrt(N) - sqrt(sum(C @ C)), PY:341-352) on a short range: line format,
+    sizes, timings and the magnitude of the reference's own error metric."""
+    out = tmp_path / "series.txt"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_series.py"), "--max", "310", "--out", str(out),
+                        "--times10", str(tmp_path / "times.txt")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [ln.split() for ln in out.read_text().strip().splitlines()]
+    assert [int(x[0]) for x in rows] == list(range(10, 310, 10))       # PY:361-366: step 10 below 2000
+    for x in rows:
+        assert len(x) == 4
+        nn, t_compute, t_total, err = int(x[0]), float(x[1]), float(x[2]), float(x[3])
+        assert 0 < t_compute <= t_total < 5.0
+        assert abs(err) < 1e-2 * np.sqrt(nn), (nn, err)   # fp32 Gauss-Jordan on U(0,100): |err| << sqrt(N)
+    trows = [ln.split() for ln in (tmp_path / "times.txt").read_text().strip().splitlines()]
+    assert len(trows) == len(rows) and all(len(x) == 11 for x in trows)
+
+
+def _dominant(n, seed, dtype):
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-1.0, 1.0, (n, n))
+    a[np.arange(n), np.arange(n)] = np.abs(a).sum(axis=1) + 1.0
+    return a.astype(dtype)
+
+
+@pytest.mark.parametrize("n", [1, 3, 64, 257, 600])
+def test_no_pivot_variant_bit_identical_to_oracle(oracle, n):
+    """matrix_inversion_no_pivots (headers.h:11, matrix_inversion_no_pivots.cpp:10): the diagonal entry is every
+    step's pivot.  fp64 through the host-pointer twin, fp32 / fp64 device-resident through a context with
+    pivoting off: bit-identical to the oracle's no-pivot restatement; a zero diagonal entry -> status 2 / {}."""
+    a64 = _dominant(n, 500 + n, np.float64)
+    want64 = oracle.matrix_inversion_no_pivots(a64, n)
+    got = g.matrix_inversion_no_pivots(a64.reshape(-1), n)
+    assert got.dtype == np.float64 and np.array_equal(got, want64)
+    inv = g.Inverter(algo="auto", pivoting=False)
+    try:
+        assert inv.resolved_algo(n, 1) == g.ALGO_SWEEP
+        x, st = inv.inv(torch.from_numpy(a64).cuda())
+        torch.cuda.synchronize()
+        assert int(st[0]) == 0 and np.array_equal(x.cpu().numpy().reshape(-1), want64)
+        a32 = a64.astype(np.float32)
+        x, st = inv.inv(torch.from_numpy(a32).cuda())
+        torch.cuda.synchronize()
+        assert int(st[0]) == 0
+        assert np.array_equal(x.cpu().numpy().reshape(-1), oracle.matrix_inversion_no_pivots(a32, n))
+        if n >= 3:
+            h = a32.copy()
+            h[1, 1] = 0.0
+            h[1, 0] = 0.0        # keeps the (1,1) entry exactly zero after step 0
+            want = oracle.matrix_inversion_no_pivots(h, n, return_info=True)[1]["status"]
+            _, st = inv.inv(torch.from_numpy(h).cuda())
+            torch.cuda.synchronize()
+            assert int(st[0]) == want == oracle.STATUS_SINGULAR
+            assert g.matrix_inversion_no_pivots(h.astype(np.float64).reshape(-1), n).size == 0
+    finally:
+        inv.close()
+    assert g.matrix_inversion_no_pivots(a64.reshape(-1), n + 1).size == 0   # the shape guards

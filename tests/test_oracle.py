@@ -233,3 +233,32 @@ def test_fp64_twin_against_numpy_and_fp32_oracle():
     assert O.matrix_inv_64(np.ones(6), 2).size == 0 and O.matrix_inv_64(np.ones(4), 0).size == 0
     _, info = O.matrix_inv_64(np.ones((4, 4)), 4, return_info=True)
     assert info["status"] == O.STATUS_SINGULAR
+
+
+def _dominant(n, seed, dtype):
+    """Strictly diagonally dominant: Gauss-Jordan needs no pivoting (the no-pivot variant's domain)."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-1.0, 1.0, (n, n))
+    a[np.arange(n), np.arange(n)] = np.abs(a).sum(axis=1) + 1.0
+    return a.astype(dtype)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 130])
+def test_no_pivot_restatement(oracle, n):
+    """matrix_inversion_no_pivots (matrix_inversion_no_pivots.cpp:10): on a diagonally dominant input true partial
+    pivoting never swaps either, so the no-pivot restatement must give the pivoting one's bits; against float64
+    NumPy within the forward bound; a zero diagonal entry -> SINGULAR (the reference returns {}, :670)."""
+    a64 = _dominant(n, 300 + n, np.float64)
+    x, info = oracle.matrix_inversion_no_pivots(a64, n, return_info=True)
+    assert info["status"] == oracle.STATUS_OK
+    assert np.array_equal(x, oracle.matrix_inv_64(a64, n))
+    assert np.abs(x.reshape(n, n) - np.linalg.inv(a64)).max() <= 1e-12 * np.abs(np.linalg.inv(a64)).max() * n
+    a32 = a64.astype(np.float32)
+    y, info = oracle.matrix_inversion_no_pivots(a32, n, return_info=True)
+    assert info["status"] == oracle.STATUS_OK and y.dtype == np.float32
+    assert np.array_equal(y, oracle.matrix_inv_32_inplace(a32, n))
+    if n >= 2:
+        h = a64.copy()
+        h[0, 0] = 0.0   # needs a swap at step 0: the no-pivot variant divides by zero
+        assert oracle.matrix_inversion_no_pivots(h, n, return_info=True)[1]["status"] == oracle.STATUS_SINGULAR
+        assert oracle.matrix_inv_64(h, n, return_info=True)[1]["status"] == oracle.STATUS_OK

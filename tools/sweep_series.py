@@ -8,7 +8,11 @@ rand()%10 inputs, `k errore`).  Same loop, same line format, same metric; the in
 the drop-in `matrix_inv_32(vec, N)` (host pointers, so t_total includes the PCIe copies exactly like
 the reference's "Tempo Totale Impiegato", and t_compute is its "Tempo Computazione").
 
-    python tools/sweep_series.py [--max 16000] [--out series.txt] [--hollow] [--coarse]
+    python tools/sweep_series.py [--max 16000] [--out series.txt] [--hollow] [--coarse] [--times10 times.txt]
+
+--times10 FILE additionally writes one line `N t0 ... t9` per size: the reference's ten-slot timing vector
+(FP32_bench.cpp:256-443: queue, buffers, build, makeAug, pivot, row, column, compute, getInverted, total) from
+the benchmark twin FP32_bench / mi32_bench_32.
 """
 import argparse
 import math
@@ -28,15 +32,22 @@ def main():
     ap.add_argument("--hollow", action="store_true", help="zero diagonal (matrix_inv_numpy.py:13-14)")
     ap.add_argument("--coarse", action="store_true", help="step 100 below 2000 instead of the reference's 10")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--times10", default="", help="also write the reference's 10-slot timing vector per size")
     args = ap.parse_args()
     out = sys.stdout if args.out == "-" else open(args.out, "w")
+    tout = open(args.times10, "w") if args.times10 else None
     rng = np.random.default_rng(args.seed)
     i = 10
     while i < args.max:
         a = rng.uniform(0, 100, (i, i)).astype(np.float32)  # PY:17
         if args.hollow:
             np.fill_diagonal(a, 0.0)
-        x = g.matrix_inv_32(a.reshape(-1), i)
+        if tout is not None:
+            x, t10 = g.fp32_bench(a.reshape(-1), i)
+            tout.write(f"{i} " + " ".join(repr(t10[k]) for k in t10) + "\n" if t10 else f"{i}" + " nan" * 10 + "\n")
+            tout.flush()
+        else:
+            x = g.matrix_inv_32(a.reshape(-1), i)
         t_total, t_compute = g.last_timing()
         if x.size == 0:
             out.write(f"{i} nan nan nan\n")
@@ -48,6 +59,8 @@ def main():
         i += (100 if args.coarse else 10) if i < 2000 else 1000            # PY:365-368
     if out is not sys.stdout:
         out.close()
+    if tout is not None:
+        tout.close()
 
 
 if __name__ == "__main__":
