@@ -205,6 +205,9 @@ def main():
                     help="N > 1: also time the batch scattered from / gathered to rank 0 over RCCL (xGMI)")
     args = ap.parse_args()
 
+    if args.algo != "auto":  # the host-pointer entry point (e2e leg) runs on the default context: same algorithm
+        os.environ["MI32_ALGO"] = {"sweep": "1", "blocked": "2"}[args.algo]
+
     import torch
     import torch.distributed as dist
 
