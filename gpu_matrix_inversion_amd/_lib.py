@@ -49,6 +49,7 @@ C_ABI_SYMBOLS = (
     "mi32_matrix_inversion_no_pivots",
     "mi32_set_pivoting",
     "mi32_inv_device_f64",
+    "mi32_resolve_blocking_f64",
     "mi32_resolve_blocking",
     "mi32_resolve_panel_widths",
     "mi32_dominant_kernel",
@@ -149,6 +150,8 @@ def load() -> ctypes.CDLL:
     lib.mi32_set_pivoting.argtypes = [vp, ctypes.c_int]
     lib.mi32_inv_device_f64.restype = ctypes.c_int
     lib.mi32_inv_device_f64.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.mi32_resolve_blocking_f64.restype = ctypes.c_int
+    lib.mi32_resolve_blocking_f64.argtypes = [vp, ctypes.c_int, ip]
     lib.mi32_resolve_panel_widths.restype = ctypes.c_int
     lib.mi32_resolve_panel_widths.argtypes = [vp, ctypes.c_int, ctypes.c_int, ip, ctypes.c_int, ip]
     lib.mi32_dominant_kernel.restype = ctypes.c_char_p

@@ -205,6 +205,12 @@ class Inverter:
                    "mi32_resolve_blocking")
         return w.value, bw.value
 
+    def resolved_blocking_f64(self, n: int) -> int:
+        """Outer block width of the fp64 blocked path for this order; 0 where the unblocked sweep runs."""
+        bw = ctypes.c_int()
+        _lib.check(self._lib.mi32_resolve_blocking_f64(self._h, int(n), ctypes.byref(bw)), "mi32_resolve_blocking_f64")
+        return bw.value
+
     def resolved_panel_widths(self, n: int, batch: int = 1):
         """Sub-panel width of every outer block (narrow while many rows are still candidates)."""
         nb = ctypes.c_int()

@@ -432,11 +432,43 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
     return MI32_OK;
 }
 
+// fp64: blocked (windowed steps + rank-bw updates on the fp64 matrix cores) from N = 256 on, measured cross-over;
+// the no-pivot variant and MI32_ALGO_SWEEP keep the unblocked sweep
+static int resolve_algo_f64(const mi32_context *h, int n)
+{
+    if (h && !h->pivoting) return MI32_ALGO_SWEEP;
+    int algo = h ? h->algo : MI32_ALGO_AUTO;
+    if (algo == MI32_ALGO_AUTO) algo = env_int("MI32_ALGO", MI32_ALGO_AUTO);
+    if (algo != MI32_ALGO_SWEEP && algo != MI32_ALGO_BLOCKED) algo = (n >= 256) ? MI32_ALGO_BLOCKED : MI32_ALGO_SWEEP;
+    return algo;
+}
+static Blocked64Plan plan_blocked64(const mi32_context *h, int n)
+{
+    return make_blocked64_plan(n, h && h->block_w ? h->block_w : env_int("MI32_BLOCK_W64", 0));
+}
+
+int mi32_resolve_blocking_f64(mi32_handle_t h, int n, int *block_width)
+{
+    if (n <= 0 || !block_width) return MI32_BAD_SHAPE;
+    *block_width = resolve_algo_f64(h, n) == MI32_ALGO_BLOCKED ? plan_blocked64(h, n).bw : 0;
+    return MI32_OK;
+}
+
 int mi32_inv_device_f64(mi32_handle_t h, const double *d_a, int n, int batch, double *d_inv, int *d_status)
 {
     if (!h || !d_a || !d_inv || n <= 0 || batch <= 0 || d_a == d_inv) return MI32_BAD_SHAPE;
     std::lock_guard<std::mutex> lk(h->mu);
     MI32_HIP(hipSetDevice(h->device));
+    if (resolve_algo_f64(h, n) == MI32_ALGO_BLOCKED) {
+        const Blocked64Plan bp = plan_blocked64(h, n);
+        int rc = ensure_ws(h, blocked64_workspace_bytes(bp, batch));
+        if (rc != MI32_OK) return rc;
+        rc = status_buffer(h, d_status, batch, &d_status);
+        if (rc != MI32_OK) return rc;
+        hipError_t eb = blocked64_invert(bp, d_a, d_inv, batch, d_status, h->ws, h->stream, h->prof);
+        if (eb != hipSuccess) return fail(eb, "kernel launch");
+        return MI32_OK;
+    }
     const SweepPlan p = make_sweep_plan(n);
     int rc = ensure_ws(h, sweep_workspace_bytes(p, batch, sizeof(double)));
     if (rc != MI32_OK) return rc;

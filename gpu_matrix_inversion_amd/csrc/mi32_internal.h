@@ -102,6 +102,18 @@ hipError_t sweep_invert(const SweepPlan &p, const float *d_a, float *d_inv, int 
 // the fp64 twin (matrix_inversion_FP64 of the reference): same launches on doubles
 hipError_t sweep_invert_f64(const SweepPlan &p, const double *d_a, double *d_inv, int batch, int *d_status, void *ws,
                             hipStream_t stream, Profiler *prof, bool pivoting = true);
+// fp64 blocked path (mi32_blocked64.hip): windowed sweep steps + rank-bw updates on the fp64 matrix cores
+struct Blocked64Plan {
+    int n, np, ld;  // matrix order, padded order (multiple of 64, identity padding), row stride in doubles
+    int bw;         // outer block width (multiple of 64, <= 256)
+    int tr;         // rows per workgroup of the step kernel (16 or 32)
+    int row_tiles;  // workgroups per step launch = arg-max records per column
+};
+Blocked64Plan make_blocked64_plan(int n, int bw);
+size_t blocked64_workspace_bytes(const Blocked64Plan &p, int batch);
+hipError_t blocked64_invert(const Blocked64Plan &p, const double *d_a, double *d_inv, int batch, int *d_status, void *ws,
+                            hipStream_t stream, Profiler *prof);
+
 // streams/events a blocked inversion is enqueued with: `aux` (may be null) carries the look-ahead half
 // of each rank-bw update; events[0 .. n/2) mark "second-stream work done", events[n/2 .. n) "panel phase done"
 struct BlockedExec {

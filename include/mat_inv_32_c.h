@@ -88,8 +88,10 @@ int mi32_reserve(mi32_handle_t h, int n, int batch);
 int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *d_inv, int *d_status);
 
 /* ---- fp64 (the reference's matrix_inversion_FP64, matrix_inversion/headers.h:9) ---------------- */
-/* Same Gauss-Jordan step sequence in double, on the sweep path (one fused launch per pivot step, HBM-bound:
- * 16 N (N+1) bytes per step); bit-identical to the oracle's fp64 restatement.  Host-pointer twin of the C++
+/* Same Gauss-Jordan step sequence in double.  N < 256: the sweep path (one fused launch per pivot step over the whole
+ * matrix, 16 N (N+1) bytes per step), bit-identical to the oracle's fp64 restatement.  N >= 256: blocked -- the same
+ * fused steps on a window of bw columns and one rank-bw update per block on v_mfma_f64_16x16x4_f64 (mi32_blocked64.hip),
+ * bit-identical to the oracle's fp64 blocked mirror.  Host-pointer twin of the C++
  * function in mat_inv_64.h, and the device-resident batched form (asynchronous on the context's stream). */
 int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor);
 /* The reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10, headers.h:11): the same steps with the
@@ -99,6 +101,10 @@ int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *in
 int mi32_matrix_inversion_no_pivots(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor);
 int mi32_set_pivoting(mi32_handle_t h, int enable);
 int mi32_inv_device_f64(mi32_handle_t h, const double *d_a, int n, int batch, double *d_inv, int *d_status);
+/* outer block width of the fp64 blocked path for this order (the step kernels run on a window of that many columns,
+ * one rank-bw update on the fp64 matrix cores per block); 0 where the unblocked sweep is used (N < 256,
+ * MI32_ALGO_SWEEP, pivoting off) */
+int mi32_resolve_blocking_f64(mi32_handle_t h, int n, int *block_width);
 
 /* Device-side verification (the reference's matrix_multiply.cpp:17-36,193-200 and
  * the residual BASELINE.json gates): per matrix, d_out[3*b+0] = ||A X - I||_inf,

@@ -25,6 +25,7 @@ from .oracle import (  # noqa: F401
     matrix_inv_32_blocked2,
     matrix_inv_32_inplace,
     matrix_inv_64,
+    matrix_inv_64_blocked,
     matrix_inversion_no_pivots,
     msvc_rand_stream,
     numpy_mirror_inv,

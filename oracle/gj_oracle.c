@@ -38,6 +38,7 @@ static inline float cand_abs(float x)
  * exact-identity check, matrix_inversion_FP32.cpp:814-835, rejects every result that went through a zero or
  * non-finite pivot): status GJO_SINGULAR when a pivot is zero, NaN or infinite, or when the INPUT holds a
  * non-finite entry (a NaN never wins the search, R:90,123, but it poisons the result). */
+static int oracle_threads(void) __attribute__((unused));
 static inline int bad_pivot(double piv) { return piv == 0.0 || piv != piv || piv - piv != 0.0; }
 static int input_status_f32(const float *in, int n)
 {
@@ -456,6 +457,106 @@ int gjo_matrix_inv_32_blocked(const float *in, size_t in_len, int n, float *out,
     return status;
 }
 
+/* ---- fp64 blocked restatement: exact CPU mirror of mi32_blocked64.hip ---------- */
+/* Outer blocks of bw pivot columns.  Inside a block the unblocked fp64 steps above (partial pivoting over the
+ * whole column height, IEEE division, one fma per element, zero multipliers skipped) run on the block's columns
+ * only; the row swaps are applied to every column right away (the HIP path applies them to the other columns
+ * lazily, through a row map: same values); after the block every other column receives one delayed rank-bw update
+ *     M[i][j] = (i in K ? 0 : M[i][j]) + sum_k G[i][k] * R[k][j],   R = the block's pivot rows as they stood,
+ * one k-ascending fma chain per element STARTING FROM THE OLD VALUE -- what a chain of v_mfma_f64_16x16x4_f64 with
+ * the old value as its C operand computes. */
+static void rank_update_row_f64(double *mi, const double *g, const double *rs, size_t n, int kw, int ja, int jb, int in_block)
+{
+    int j = ja;
+#if defined(__AVX2__) && defined(__FMA__)
+    for (; j + 32 <= jb; j += 32) {
+        __m256d acc[8];
+        for (int v = 0; v < 8; ++v) acc[v] = in_block ? _mm256_setzero_pd() : _mm256_loadu_pd(mi + j + 4 * v);
+        for (int k = 0; k < kw; ++k) {
+            const __m256d b = _mm256_set1_pd(g[k]);
+            const double *r = rs + (size_t)k * n + j;
+            for (int v = 0; v < 8; ++v) acc[v] = _mm256_fmadd_pd(b, _mm256_loadu_pd(r + 4 * v), acc[v]);
+        }
+        for (int v = 0; v < 8; ++v) _mm256_storeu_pd(mi + j + 4 * v, acc[v]);
+    }
+#endif
+    for (; j < jb; ++j) {
+        double acc = in_block ? 0.0 : mi[j];
+        for (int k = 0; k < kw; ++k) acc = fma(g[k], rs[(size_t)k * n + j], acc);
+        mi[j] = acc;
+    }
+}
+
+int gjo_matrix_inv_64_blocked(const double *in, size_t in_len, int n, double *out, int bw, int *pivots)
+{
+    if (!shape_ok(in_len, n)) return GJO_BAD_SHAPE;
+    if (bw <= 0) return GJO_BAD_SHAPE;
+    const size_t ld = (size_t)n;
+    double *m = (double *)malloc(sizeof(double) * ld * n);
+    int *orig = (int *)malloc(sizeof(int) * n);
+    double *rs = (double *)malloc(sizeof(double) * (size_t)bw * n);
+    double *rowr = (double *)malloc(sizeof(double) * bw);
+    if (!m || !orig || !rs || !rowr) {
+        free(m); free(orig); free(rs); free(rowr);
+        return GJO_BAD_SHAPE;
+    }
+    memcpy(m, in, sizeof(double) * ld * n);
+    for (int i = 0; i < n; ++i) orig[i] = i;
+    int status = input_status_f64(in, n);
+    for (int c0 = 0; c0 < n; c0 += bw) {
+        const int kw = (c0 + bw <= n) ? bw : n - c0;
+        for (int s = 0; s < kw; ++s) { /* the steps of inv64_inplace_impl on the columns [c0, c0 + kw) */
+            const int r = c0 + s;
+            int p = r;
+            double best = -1.0;
+            for (int i = r; i < n; ++i) {
+                const double v = fabs(m[(size_t)i * ld + r]);
+                if (v > best) { best = v; p = i; }
+            }
+            const double piv = m[(size_t)p * ld + r];
+            if (pivots) pivots[r] = p;
+            if (bad_pivot(piv)) status = GJO_SINGULAR;
+            if (p != r) {
+                for (int j = 0; j < n; ++j) {
+                    double t = m[(size_t)r * ld + j];
+                    m[(size_t)r * ld + j] = m[(size_t)p * ld + j];
+                    m[(size_t)p * ld + j] = t;
+                }
+                int t = orig[r]; orig[r] = orig[p]; orig[p] = t;
+            }
+            double *mr = m + (size_t)r * ld + c0;
+            for (int c = 0; c < kw; ++c) mr[c] = mr[c] / piv;
+            mr[s] = 1.0 / piv;
+            memcpy(rowr, mr, sizeof(double) * kw);
+            for (int i = 0; i < n; ++i) {
+                if (i == r) continue;
+                double *mi = m + (size_t)i * ld + c0;
+                const double cir = mi[s];
+                mi[s] = 0.0;
+                if (cir != 0.0)
+                    for (int c = 0; c < kw; ++c) mi[c] = fma(-cir, rowr[c], mi[c]);
+            }
+        }
+        if (kw < n) {
+            for (int k = 0; k < kw; ++k) memcpy(rs + (size_t)k * n, m + (size_t)(c0 + k) * ld, sizeof(double) * n);
+#ifdef _OPENMP
+            const int nthreads = ((double)n * kw * n > 4e7) ? oracle_threads() : 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+            for (int i = 0; i < n; ++i) {
+                double *mi = m + (size_t)i * ld;
+                const int in_block = (i >= c0 && i < c0 + kw);
+                if (c0 > 0) rank_update_row_f64(mi, mi + c0, rs, (size_t)n, kw, 0, c0, in_block);
+                if (c0 + kw < n) rank_update_row_f64(mi, mi + c0, rs, (size_t)n, kw, c0 + kw, n, in_block);
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < n; ++c) out[(size_t)i * n + orig[c]] = m[(size_t)i * ld + c];
+    free(m); free(orig); free(rs); free(rowr);
+    return status;
+}
+
 /* ---- two-level blocked restatement: exact CPU mirror of mi32_blocked.hip ----- */
 /* Outer blocks of bw pivot columns; inside a block, sub-panels of w columns are
  * reduced with the unblocked steps and followed by a rank-w update of the block's
@@ -506,7 +607,7 @@ static void rank_update_row(float *mi, const float *g, const float *rs, size_t n
     }
 }
 
-static int __attribute__((unused)) oracle_threads(void)
+static int oracle_threads(void)
 {
 #ifdef _OPENMP
     const char *e = getenv("GJO_THREADS");

@@ -74,6 +74,10 @@ int gjo_matrix_inv_32_inplace(const float *in, size_t in_len, int n, float *out,
  * true partial pivoting and one fma per element. */
 int gjo_matrix_inv_64_inplace(const double *in, size_t in_len, int n, double *out, int *pivots);
 
+/* fp64 blocked restatement (outer blocks of bw pivot columns, one delayed rank-bw update per block whose fma
+ * chains start from the old value): the CPU mirror of the HIP fp64 blocked path's operation order. */
+int gjo_matrix_inv_64_blocked(const double *in, size_t in_len, int n, double *out, int bw, int *pivots);
+
 /* The reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10; headers.h:11): the pivot of step r is the
  * diagonal entry; fp64 as the reference ships it, and the same steps in fp32. */
 int gjo_matrix_inv_64_nopivot(const double *in, size_t in_len, int n, double *out);

@@ -73,6 +73,8 @@ def _load():
     dp = ctypes.POINTER(ctypes.c_double)
     lib.gjo_matrix_inv_64_inplace.restype = ctypes.c_int
     lib.gjo_matrix_inv_64_inplace.argtypes = [dp, ctypes.c_size_t, ctypes.c_int, dp, ip]
+    lib.gjo_matrix_inv_64_blocked.restype = ctypes.c_int
+    lib.gjo_matrix_inv_64_blocked.argtypes = [dp, ctypes.c_size_t, ctypes.c_int, dp, ctypes.c_int, ip]
     lib.gjo_matrix_inv_64_nopivot.restype = ctypes.c_int
     lib.gjo_matrix_inv_64_nopivot.argtypes = [dp, ctypes.c_size_t, ctypes.c_int, dp]
     lib.gjo_matrix_inv_32_nopivot.restype = ctypes.c_int
@@ -170,6 +172,22 @@ def matrix_inv_32_blocked(vec, n: int, w: int = 16, return_info: bool = False):
     if return_info:
         return out, {"status": st, "pivots": piv}
     return out
+
+
+def matrix_inv_64_blocked(vec, n: int, bw: int, return_info: bool = False):
+    """fp64 blocked mirror (outer blocks of bw columns, delayed rank-bw updates): the HIP fp64 blocked path's order."""
+    lib = _load()
+    v = np.ascontiguousarray(np.asarray(vec, dtype=np.float64).reshape(-1))
+    n = int(n)
+    if n <= 0 or int(v.size // n) != n:
+        empty = np.empty(0, dtype=np.float64)
+        return (empty, {"status": STATUS_BAD_SHAPE}) if return_info else empty
+    out = np.empty(n * n, dtype=np.float64)
+    piv = np.empty(n, dtype=np.int32)
+    dp = ctypes.POINTER(ctypes.c_double)
+    st = lib.gjo_matrix_inv_64_blocked(v.ctypes.data_as(dp), v.size, n, out.ctypes.data_as(dp), int(bw),
+                                       piv.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    return (out, {"status": st, "pivots": piv}) if return_info else out
 
 
 def matrix_inversion_no_pivots(vec, n: int, return_info: bool = False):

@@ -270,9 +270,68 @@ def test_fp64_sweep_bit_identical_to_fp64_oracle(oracle, inv_sweep, n):
         torch.cuda.synchronize()
         assert int(st[0]) == info["status"] == 0
         assert np.array_equal(x.cpu().numpy().reshape(-1), want), (kind, n)
-    got = g.matrix_inv_64(a.reshape(-1), n)
-    assert got.dtype == np.float64 and np.array_equal(got, want)
+    got = g.matrix_inv_64(a.reshape(-1), n)   # the host-pointer twin, AUTO: blocked from N = 256 on
+    bw = _default_f64_block_width(n)
+    want_host = want if bw == 0 else oracle.matrix_inv_64_blocked(a, n, bw)
+    assert got.dtype == np.float64 and np.array_equal(got, want_host)
     assert g.matrix_inv_64(np.ones((4, 4)).reshape(-1), 4).size == 0   # singular -> empty, like the reference
+
+
+def _default_f64_block_width(n):
+    inv = g.Inverter(algo="auto")
+    try:
+        return inv.resolved_blocking_f64(n)
+    finally:
+        inv.close()
+
+
+@pytest.mark.parametrize("n", [256, 257, 300, 512, 700, 1000, 1500])
+def test_fp64_blocked_bit_identical_to_fp64_blocked_mirror(oracle, n):
+    """The fp64 blocked path (windowed fused steps + one rank-bw update per block on v_mfma_f64_16x16x4_f64,
+    matrix_inversion_FP64 of the reference from N = 256 on): bit-identical to the oracle's fp64 blocked mirror
+    (gjo_matrix_inv_64_blocked: same block width, fma chains starting from the old value), for the default block
+    width and the two others; and within 1e-11 of the unblocked fp64 result."""
+    for bw_req in (0, 64, 256):
+        inv = g.Inverter(algo="auto", block_width=bw_req)
+        try:
+            bw = inv.resolved_blocking_f64(n)
+            assert bw in (64, 128, 256) and (bw_req == 0 or bw == min(bw_req, 256) or n < bw_req)
+            for kind in ("gate", "ref100", "hollow"):
+                a = dist_matrix(kind, n, 9500 + n).astype(np.float64)
+                want, info = oracle.matrix_inv_64_blocked(a, n, bw, return_info=True)
+                x, st = inv.inv(torch.from_numpy(a).cuda())
+                torch.cuda.synchronize()
+                assert int(st[0]) == info["status"] == 0
+                got = x.cpu().numpy().reshape(-1)
+                assert np.array_equal(got, want), (kind, n, bw, np.abs(got - want).max())
+                ref = oracle.matrix_inv_64(a, n)
+                assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+        finally:
+            inv.close()
+
+
+def test_fp64_blocked_4096_residual_and_speed(oracle):
+    """N = 4096 in double through the blocked path: residual at fp64 level, bit-identical to the mirror."""
+    n = 4096
+    a = gate_matrix(n, 60_001).astype(np.float64)
+    inv = g.Inverter(algo="auto")
+    try:
+        bw = inv.resolved_blocking_f64(n)
+        ta = torch.from_numpy(a).cuda()
+        x, st = inv.inv(ta)
+        torch.cuda.synchronize()
+        res = float((ta @ x - torch.eye(n, dtype=torch.float64, device="cuda")).abs().sum(dim=1).max())
+        assert int(st[0]) == 0 and res < 1e-10, res
+        want = oracle.matrix_inv_64_blocked(a, n, bw)
+        assert np.array_equal(x.cpu().numpy().reshape(-1), want)
+        # a singular / non-finite member of a batch is flagged, the others are untouched
+        b3 = torch.stack([ta[:512, :512].contiguous(), torch.ones(512, 512, dtype=torch.float64, device="cuda"),
+                          ta[512:1024, 512:1024].contiguous()])
+        _, st3 = inv.inv(b3)
+        torch.cuda.synchronize()
+        assert st3.tolist() == [0, 2, 0]
+    finally:
+        inv.close()
 
 
 def test_fp64_1024_residual(inv_sweep):
