@@ -14,6 +14,29 @@
 
 using namespace mi32;
 
+// experiment: persistent grid walking the tiles, WPC workgroups per CU, optional one-time start stagger
+template <int BK, int WPC>
+__global__ __launch_bounds__(256, WPC) void rb_persistent_exp_kernel(
+    const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
+    const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
+    const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int stagger_cycles)
+{
+    extern __shared__ __attribute__((aligned(16))) float rb_smem[];
+    const int T = np / 128;
+    if (stagger_cycles > 0) {
+        const int slot = (int)(blockIdx.x / 256) % WPC;   // workgroups b and b + 256 tend to share a CU
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)slot * stagger_cycles) __builtin_amdgcn_s_sleep(8);
+    }
+    for (int id = blockIdx.x; id < T * T; id += gridDim.x) {
+        int rt, ct;
+        rb_tile_of(id, T, T, rt, ct);
+        rank_bw2_tile<BK>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
+                          copy_panel, ex, tstride, 0, 0, blockIdx.y, rt, ct, rb_smem);
+        __syncthreads();
+    }
+}
+
 #ifdef MI32_RB_STAMPS
 __global__ void set_stamp_buffer(unsigned long long *p) { mi32::g_rb_stamps = p; }
 #endif
@@ -86,6 +109,16 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL((gj_rank_bw2_kernel<RB_BK, RB_WPS, RB_BN>), dim3(T * (np / RB_BN), batch), dim3(256), lds2, 0, src, d2, g, mstride, gk,
                            gkstride, np, ld, mstride, c0, kdim, map, 1, PanelExport{pt2, 0, pt_col, pt_w, 1}, tstride, 0, 0, (const int *)nullptr);
     };
+    CK(hipFuncSetAttribute((const void *)rb_persistent_exp_kernel<RB_BK, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    CK(hipFuncSetAttribute((const void *)rb_persistent_exp_kernel<RB_BK, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    auto runP = [&](int wpc, int stagger) {
+        if (wpc == 4)
+            hipLaunchKernelGGL((rb_persistent_exp_kernel<RB_BK, 4>), dim3(256 * 4, batch), dim3(256), lds2, 0, src, d2, g, mstride, gk,
+                               gkstride, np, ld, mstride, c0, kdim, map, 1, PanelExport{pt2, 0, pt_col, pt_w, 1}, tstride, stagger);
+        else
+            hipLaunchKernelGGL((rb_persistent_exp_kernel<RB_BK, 3>), dim3(256 * 3, batch), dim3(256), lds2, 0, src, d2, g, mstride, gk,
+                               gkstride, np, ld, mstride, c0, kdim, map, 1, PanelExport{pt2, 0, pt_col, pt_w, 1}, tstride, stagger);
+    };
     run1(); runT(); run2();
     CK(hipDeviceSynchronize());
     CK(hipGetLastError());
@@ -144,6 +177,14 @@ int main(int argc, char **argv)
     for (int round = 0; round < 3; ++round) {  // interleaved A/B rounds in one process
         time_it("gen2 update", run2old);
         time_it("gen2 update (again)", run2);
+    }
+    for (int round = 0; round < 1; ++round) {
+        time_it("persistent 4/CU", [&]() { runP(4, 0); });
+        time_it("persistent 4/CU stagger 10k", [&]() { runP(4, 10000); });
+        time_it("persistent 4/CU stagger 30k", [&]() { runP(4, 30000); });
+        time_it("persistent 3/CU", [&]() { runP(3, 0); });
+        time_it("persistent 3/CU stagger 40k", [&]() { runP(3, 40000); });
+        time_it("gen2 update", run2);
     }
     time_it("gen2 transpose+update", [&]() { runT(); run2(); });
     return bad != 0 || !pt_same;
