@@ -24,6 +24,13 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gpu_matrix_inversion_amd as g  # noqa: E402
 
+try:  # only the error metric of the large sizes uses torch (the checker, not the inversion)
+    import torch as _torch
+    if not _torch.cuda.is_available():
+        _torch = None
+except Exception:  # pragma: no cover
+    _torch = None
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -52,8 +59,14 @@ def main():
         if x.size == 0:
             out.write(f"{i} nan nan nan\n")
         else:
-            c = x.reshape(i, i).astype(np.float64) @ a.astype(np.float64)  # PY:341  C = inv * A
-            err = math.sqrt(i) - math.sqrt(abs(float(np.sum(c @ c))))     # PY:342-345 (matrix product c @ c)
+            if i >= 1500 and _torch is not None:  # the checker's two float64 products on the GPU (8 TFLOP at N = 16000)
+                tx = _torch.from_numpy(x.reshape(i, i)).cuda().double()
+                c = tx @ _torch.from_numpy(a).cuda().double()                 # PY:341  C = inv * A
+                err = math.sqrt(i) - math.sqrt(abs(float((c @ c).sum())))      # PY:342-345 (matrix product c @ c)
+                del tx, c
+            else:
+                c = x.reshape(i, i).astype(np.float64) @ a.astype(np.float64)  # PY:341  C = inv * A
+                err = math.sqrt(i) - math.sqrt(abs(float(np.sum(c @ c))))     # PY:342-345 (matrix product c @ c)
             out.write(f"{i} {t_compute} {t_total} {err}\n")                 # PY:352
         out.flush()
         i += (100 if args.coarse else 10) if i < 2000 else 1000            # PY:365-368
