@@ -6,7 +6,7 @@
 // :193-200) and of the residual BASELINE.json gates: ||A X - I||_inf.
 // Per matrix b:  out[3b+0] = ||A X - I||_inf,  out[3b+1] = ||X A - I||_inf,
 //                out[3b+2] = sqrt(N) - ||A X||_F.
-// fp32 operands are widened to fp64 in registers; products and sums are fp64.
+// fp32 operands are widened to fp64 in registers; products and sums are fp64, on v_mfma_f64_16x16x4_f64.
 #include "mi32_internal.h"
 
 namespace mi32 {
@@ -15,14 +15,18 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // workspace: per matrix rowsum_right[n], rowsum_left[n], sumsq (doubles)
 size_t residual_workspace_bytes(int n, int batch) { return align256(((size_t)2 * n + 2) * sizeof(double) * batch); }
 
-// C = L * R (n x n), 64x64 tile per workgroup, 4x4 outputs per thread.
+// C = L * R (n x n) on the fp64 matrix cores: 64 x 64 tile per workgroup, 4 waves (2 x 2), each 32 x 32 = 2 x 2 tiles
+// of v_mfma_f64_16x16x4_f64 (A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15], D[row = (lane >> 4) + 4 reg][col =
+// lane & 15]); the fp32 operands are widened to fp64 on their way from LDS, so every product is exact and every
+// element is one k-ascending fp64 fma chain.
 // which = 0: right residual (L=A, R=X) also accumulates sum of squares of C.
+typedef double res_d4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void residual_tile_kernel(const float *__restrict__ l_all,
                                                              const float *__restrict__ r_all, int n,
                                                              double *__restrict__ ws, int which)
 {
     __shared__ float s_l[16][65];  // [k][i]
-    __shared__ float s_r[16][64];  // [k][j]
+    __shared__ float s_r[16][65];  // [k][j]
     __shared__ double s_sq[4];
     const int b = blockIdx.z;
     const float *L = l_all + (size_t)b * n * n;
@@ -30,60 +34,79 @@ __global__ __launch_bounds__(256) void residual_tile_kernel(const float *__restr
     double *rowsum = ws + (size_t)b * (2 * (size_t)n + 2) + (which ? n : 0);
     double *sumsq = ws + (size_t)b * (2 * (size_t)n + 2) + 2 * (size_t)n;
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
     const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-    double acc[4][4];
+    res_d4v acc[2][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[u][v][q] = 0.0;
 
     for (int k0 = 0; k0 < n; k0 += 16) {
-        // L tile: 64 rows x 16 k
-        for (int idx = tid; idx < 64 * 16; idx += 256) {
-            const int ii = idx >> 4, kk = idx & 15;
-            const int gi = i0 + ii, gk = k0 + kk;
-            s_l[kk][ii] = (gi < n && gk < n) ? L[(size_t)gi * n + gk] : 0.0f;
-        }
-        for (int idx = tid; idx < 16 * 64; idx += 256) {
-            const int kk = idx >> 6, jj = idx & 63;
-            const int gk = k0 + kk, gj = j0 + jj;
-            s_r[kk][jj] = (gk < n && gj < n) ? R[(size_t)gk * n + gj] : 0.0f;
+        if ((n & 3) == 0) {  // rows are 16-byte aligned: one 16-byte load per thread and operand
+            typedef float res_f4v __attribute__((ext_vector_type(4)));
+            const int ii = tid >> 2, k4 = (tid & 3) * 4;   // L tile: 64 rows x 16 k
+            res_f4v v = (res_f4v)(0.0f);
+            if (i0 + ii < n && k0 + k4 < n) v = *reinterpret_cast<const res_f4v *>(L + (size_t)(i0 + ii) * n + k0 + k4);
+            s_l[k4 + 0][ii] = v[0]; s_l[k4 + 1][ii] = v[1]; s_l[k4 + 2][ii] = v[2]; s_l[k4 + 3][ii] = v[3];
+            const int kk = tid >> 4, j4 = (tid & 15) * 4;   // R tile: 16 k x 64 j
+            res_f4v w = (res_f4v)(0.0f);
+            if (k0 + kk < n && j0 + j4 < n) w = *reinterpret_cast<const res_f4v *>(R + (size_t)(k0 + kk) * n + j0 + j4);
+            s_r[kk][j4 + 0] = w[0]; s_r[kk][j4 + 1] = w[1]; s_r[kk][j4 + 2] = w[2]; s_r[kk][j4 + 3] = w[3];
+        } else {
+            for (int idx = tid; idx < 64 * 16; idx += 256) {   // L tile: 64 rows x 16 k
+                const int ii = idx >> 4, kk = idx & 15;
+                const int gi = i0 + ii, gk = k0 + kk;
+                s_l[kk][ii] = (gi < n && gk < n) ? L[(size_t)gi * n + gk] : 0.0f;
+            }
+            for (int idx = tid; idx < 16 * 64; idx += 256) {
+                const int kk = idx >> 6, jj = idx & 63;
+                const int gk = k0 + kk, gj = j0 + jj;
+                s_r[kk][jj] = (gk < n && gj < n) ? R[(size_t)gk * n + gj] : 0.0f;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            double lv[4], rv[4];
+        for (int kk = 0; kk < 16; kk += 4) {
+            double lv[2], rv[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) lv[u] = (double)s_l[kk][ty * 4 + u];
+            for (int q = 0; q < 2; ++q) {
+                lv[q] = (double)s_l[kk + l4][wr * 32 + q * 16 + l15];
+                rv[q] = (double)s_r[kk + l4][wc * 32 + q * 16 + l15];
+            }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) rv[v] = (double)s_r[kk][tx * 4 + v];
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] = fma(lv[u], rv[v], acc[u][v]);
+                for (int v = 0; v < 2; ++v)
+                    acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[u], rv[v], acc[u][v], 0, 0, 0);
         }
         __syncthreads();
     }
     double sq = 0.0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int gi = i0 + ty * 4 + u;
-        double rs = 0.0;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int gj = j0 + tx * 4 + v;
-            if (gi < n && gj < n) {
-                const double c = acc[u][v];
-                sq += c * c;
-                rs += fabs(c - (gi == gj ? 1.0 : 0.0));
+        for (int q = 0; q < 4; ++q) {
+            const int gi = i0 + wr * 32 + u * 16 + l4 + 4 * q;
+            double rs = 0.0;
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int gj = j0 + wc * 32 + v * 16 + l15;
+                if (gi < n && gj < n) {
+                    const double c = acc[u][v][q];
+                    sq += c * c;
+                    rs += fabs(c - (gi == gj ? 1.0 : 0.0));
+                }
             }
-        }
-        // the 16 threads of one ty are 16 consecutive lanes
+            // the 16 lanes that share l4 hold the 16 columns of this row: consecutive lanes
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
-        if (tx == 0 && gi < n) atomicAdd(&rowsum[gi], rs);
-    }
+            for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+            if (l15 == 0 && gi < n) atomicAdd(&rowsum[gi], rs);
+        }
     if (which == 0) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
