@@ -7,6 +7,7 @@
 // of its 4.37 s at N=4096) and tears them down again (:388), this keeps one
 // AOT-compiled code object, one stream and one grow-only workspace per context.
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mat_inv_32.h"
@@ -73,8 +75,148 @@ struct EventProfiler : public Profiler {
     }
 };
 
+// Host <-> device copies of the host-pointer entry points.  The caller's vectors are pageable memory: a plain
+// hipMemcpy moves 64 MiB (N = 4096) in 4.6 ms each way on this platform, while the DMA engine needs 1.2 ms from
+// pinned memory and pinning the caller's pages (hipHostRegister) costs 4 ms by itself (tools/h2d_probe.hip).
+// So: kLanes host threads, each with two pinned 2 MiB buffers and a stream of its own, memcpy chunk i + 1 into one
+// buffer while the DMA engine drains chunk i from the other: N = 4096 end to end 16.8-21.6 -> 12.4 ms (8.8 ms of it
+// compute), N = 8192 65 -> 52 ms.
+struct HostCopier {
+    static constexpr int kLanes = 6;
+    static constexpr size_t kChunk = 2u << 20;
+    static constexpr size_t kMinBytes = 32u << 20;  // below this a plain hipMemcpyAsync wins (measured cross-over)
+    char *pin[kLanes][2] = {};
+    hipStream_t stream[kLanes] = {};
+    hipEvent_t ev[kLanes][2] = {};
+    // the lanes are persistent threads (a fresh thread's first HIP call costs more than the copy it would do)
+    std::thread th[kLanes];
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    unsigned long long job_id = 0;  // incremented per job; a lane runs job j when job_id == j > its last one
+    int pending = 0;
+    bool quit = false;
+    int device = 0;
+    void *j_dev = nullptr, *j_host = nullptr;
+    size_t j_bytes = 0;
+    bool j_to_device = true;
+    hipError_t j_err[kLanes];
+    bool ready = false;
+
+    hipError_t init(int dev)
+    {
+        if (ready) return hipSuccess;
+        device = dev;
+        for (int t = 0; t < kLanes; ++t) {
+            hipError_t e = hipStreamCreateWithFlags(&stream[t], hipStreamNonBlocking);
+            if (e != hipSuccess) return e;
+            for (int q = 0; q < 2; ++q) {
+                if ((e = hipHostMalloc((void **)&pin[t][q], kChunk, hipHostMallocDefault)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&ev[t][q], hipEventDisableTiming)) != hipSuccess) return e;
+            }
+        }
+        for (int t = 0; t < kLanes; ++t) th[t] = std::thread([this, t]() { lane_main(t); });
+        ready = true;
+        return hipSuccess;
+    }
+    void destroy()
+    {
+        if (!ready) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv_job.notify_all();
+        for (int t = 0; t < kLanes; ++t)
+            if (th[t].joinable()) th[t].join();
+        for (int t = 0; t < kLanes; ++t) {
+            for (int q = 0; q < 2; ++q) {
+                if (pin[t][q]) (void)hipHostFree(pin[t][q]);
+                if (ev[t][q]) (void)hipEventDestroy(ev[t][q]);
+            }
+            if (stream[t]) (void)hipStreamDestroy(stream[t]);
+        }
+        ready = false;
+    }
+    void lane_main(int t)
+    {
+        (void)hipSetDevice(device);
+        unsigned long long done_id = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&]() { return quit || job_id != done_id; });
+                if (quit) return;
+                done_id = job_id;
+            }
+            j_err[t] = lane_copy(t);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    hipError_t lane_copy(int t)
+    {
+        const size_t bytes = j_bytes;
+        const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+        char *dev = (char *)j_dev, *host = (char *)j_host;
+        auto span = [&](size_t c, size_t &off, size_t &len) { off = c * kChunk; len = bytes - off < kChunk ? bytes - off : kChunk; };
+        hipError_t e = hipSuccess;
+        size_t k = 0;  // this lane's chunk counter
+        if (j_to_device) {
+            for (size_t c = t; c < nchunks && e == hipSuccess; c += kLanes, ++k) {
+                size_t off, len;
+                span(c, off, len);
+                const int q = (int)(k & 1);
+                if (k >= 2) e = hipEventSynchronize(ev[t][q]);  // the DMA that last read this buffer
+                if (e != hipSuccess) break;
+                std::memcpy(pin[t][q], host + off, len);
+                e = hipMemcpyAsync(dev + off, pin[t][q], len, hipMemcpyHostToDevice, stream[t]);
+                if (e == hipSuccess) e = hipEventRecord(ev[t][q], stream[t]);
+            }
+        } else {
+            size_t off, len;
+            if ((size_t)t < nchunks) {
+                span(t, off, len);
+                e = hipMemcpyAsync(pin[t][0], dev + off, len, hipMemcpyDeviceToHost, stream[t]);
+                if (e == hipSuccess) e = hipEventRecord(ev[t][0], stream[t]);
+            }
+            for (size_t c = t; c < nchunks && e == hipSuccess; c += kLanes, ++k) {
+                const int q = (int)(k & 1);
+                if (c + kLanes < nchunks) {  // the next chunk of this lane into the other buffer
+                    size_t noff, nlen;
+                    span(c + kLanes, noff, nlen);
+                    e = hipMemcpyAsync(pin[t][q ^ 1], dev + noff, nlen, hipMemcpyDeviceToHost, stream[t]);
+                    if (e == hipSuccess) e = hipEventRecord(ev[t][q ^ 1], stream[t]);
+                    if (e != hipSuccess) break;
+                }
+                span(c, off, len);
+                e = hipEventSynchronize(ev[t][q]);
+                if (e != hipSuccess) break;
+                std::memcpy(host + off, pin[t][q], len);
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream[t]);
+        return e;
+    }
+    // to_device: dev <- host, else host <- dev.  Synchronous: returns when every byte has arrived.
+    hipError_t run(void *dev, void *host, size_t bytes, bool to_device)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        j_dev = dev; j_host = host; j_bytes = bytes; j_to_device = to_device;
+        pending = kLanes;
+        ++job_id;
+        cv_job.notify_all();
+        cv_done.wait(lk, [&]() { return pending == 0; });
+        for (int t = 0; t < kLanes; ++t)
+            if (j_err[t] != hipSuccess) return j_err[t];
+        return hipSuccess;
+    }
+};
+
 struct mi32_context {
     int device = 0;
+    HostCopier copier;
     EventProfiler *prof = nullptr;
     hipEvent_t switch_event = nullptr;
     hipStream_t aux_stream = nullptr;   // look-ahead half of the rank-bw updates (lowest priority)
@@ -267,6 +409,7 @@ int mi32_destroy(mi32_handle_t h)
     if (h->d_out) (void)hipFree(h->d_out);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->d_istatus) (void)hipFree(h->d_istatus);
+    h->copier.destroy();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->switch_event) (void)hipEventDestroy(h->switch_event);
     if (h->aux_stream) {
@@ -554,6 +697,22 @@ static int ensure_io(mi32_context *h, size_t floats, size_t ints)
     return MI32_OK;
 }
 
+// dev <- host (to_device) or host <- dev; synchronous.  Large transfers go through the pinned ring of HostCopier
+// (MI32_HOST_COPY=0 keeps the runtime's pageable path), small ones through one hipMemcpyAsync.
+static int host_copy(mi32_context *h, void *dev, void *host, size_t bytes, bool to_device)
+{
+    if (bytes >= HostCopier::kMinBytes && env_int("MI32_HOST_COPY", 1) != 0) {
+        MI32_HIP(h->copier.init(h->device));
+        MI32_HIP(hipStreamSynchronize(h->stream));  // the lanes' streams are not ordered with the context's stream
+        MI32_HIP(h->copier.run(dev, host, bytes, to_device));
+        return MI32_OK;
+    }
+    if (to_device) MI32_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream));
+    else MI32_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    MI32_HIP(hipStreamSynchronize(h->stream));
+    return MI32_OK;
+}
+
 // The host-pointer path.  times10 (may be NULL): the reference's timing vector, FP32_bench.cpp:256-443 /
 // res_struct.h:4-6 -- [0] queue/context, [1] buffers (+ the H2D copy the reference's CL_MEM_COPY_HOST_PTR does),
 // [2] program build, [3] makeAugmented, [4] pivot, [5] row, [6] column, [7] compute, [8] getInverted (+ D2H),
@@ -579,8 +738,8 @@ static int host_invert_32(const float *a, int n, int batch, float *inv, int *sta
         double ms[KC_COUNT]; long long cnt[KC_COUNT];
         (void)mi32_get_profile(h, ms, cnt, KC_COUNT);  // drop what an earlier call left
     }
-    MI32_HIP(hipMemcpyAsync(h->d_in, a, floats * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    MI32_HIP(hipStreamSynchronize(h->stream));
+    rc = host_copy(h, h->d_in, const_cast<float *>(a), floats * sizeof(float), true);
+    if (rc != MI32_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     rc = mi32_inv_device(h, h->d_in, n, batch, h->d_out, h->d_status);
     if (rc != MI32_OK) return rc;
@@ -588,7 +747,8 @@ static int host_invert_32(const float *a, int n, int batch, float *inv, int *sta
     const auto t2 = std::chrono::steady_clock::now();
     std::vector<int> st((size_t)batch);
     MI32_HIP(hipMemcpyAsync(st.data(), h->d_status, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    MI32_HIP(hipMemcpyAsync(inv, h->d_out, floats * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    rc = host_copy(h, h->d_out, inv, floats * sizeof(float), false);
+    if (rc != MI32_OK) return rc;
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t3 = std::chrono::steady_clock::now();
     g_last_total = std::chrono::duration<double>(t3 - t0).count();
@@ -677,8 +837,8 @@ static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double 
     rc = ensure_io(h, 2 * elems, 1);  // doubles: two 4-byte units each
     if (rc != MI32_OK) return rc;
     double *din = reinterpret_cast<double *>(h->d_in), *dout = reinterpret_cast<double *>(h->d_out);
-    MI32_HIP(hipMemcpyAsync(din, a_rowmajor, elems * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    MI32_HIP(hipStreamSynchronize(h->stream));
+    rc = host_copy(h, din, const_cast<double *>(a_rowmajor), elems * sizeof(double), true);
+    if (rc != MI32_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     {
         const bool saved = h->pivoting;  // the default context is only ever used under g_host_call_mu
@@ -691,7 +851,8 @@ static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double 
     const auto t2 = std::chrono::steady_clock::now();
     int st = MI32_OK;
     MI32_HIP(hipMemcpyAsync(&st, h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    MI32_HIP(hipMemcpyAsync(inv_rowmajor, dout, elems * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    rc = host_copy(h, dout, inv_rowmajor, elems * sizeof(double), false);
+    if (rc != MI32_OK) return rc;
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t3 = std::chrono::steady_clock::now();
     g_last_total = std::chrono::duration<double>(t3 - t0).count();
