@@ -483,6 +483,24 @@ def test_c1_4096_default_plan_bit_identical_to_mirror(oracle):
     check_against_mirror_digest(got, dig)
 
 
+@pytest.mark.parametrize("kind", ["ref100", "rand", "hollow"])
+def test_c1_4096_reference_distributions_bit_identical_to_mirror(oracle, kind):
+    """N = 4096 on the reference's own input distributions (U(0,100) of matrix_inv_pyopencl.py:17 / matrix_inv_numpy.py:40,
+    MATLAB rand, the hollow variant of main_file.cpp:46-48): far worse conditioned than D_gate -- different pivot
+    sequences, large growth -- and still bit for bit the oracle's blocked mirror."""
+    n = 4096
+    a = dist_matrix(kind, n, 4096_000 + len(kind))
+    inv = _default_inverter()
+    try:
+        widths, bw = inv.resolved_panel_widths(n, 1), inv.resolved_blocking(n, 1)[1]
+        got, st = run(inv, a)
+    finally:
+        inv.close()
+    want, info = oracle.matrix_inv_32_blocked2(a, n, widths, bw, return_info=True)
+    assert st[0] == info["status"] == 0
+    assert np.array_equal(got.reshape(-1), want), (kind, np.abs(got.reshape(-1) - want).max())
+
+
 @pytest.mark.parametrize("n", [8200, 16384])
 def test_shared_panel_sizes_bit_identical_to_mirror_digest(n):
     """N = 8200 (8320 padded rows: three workgroups share the first panels) and N = 16384 = BASELINE configs[4]
