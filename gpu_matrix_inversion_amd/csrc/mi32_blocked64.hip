@@ -21,6 +21,8 @@
 // Working matrix: the N x N in-place form padded with an identity block to a multiple of 64 (no bounds checks in the
 // tiles: inv(diag(A, I)) = diag(inv(A), I); a real column never takes its pivot from the padding, whose entries
 // in real columns are exact zeros).
+#include <cstdlib>
+
 #include "mi32_internal.h"
 #include "mi32_sweep_common.h"
 
@@ -29,8 +31,9 @@ namespace mi32 {
 typedef double b64_d4v __attribute__((ext_vector_type(4)));
 
 static constexpr int kB64Threads = 256;
-// rows per workgroup of the step kernel: 16 up to N = 4096 (more, shorter workgroups: the step is a chain of
-// dependent round trips), 32 above (every workgroup reduces one arg-max record per row tile: N / TR of them)
+// rows per workgroup of the step kernel: 8 up to N = 4096 (more, shorter workgroups: the step is a chain of
+// dependent round trips), 32 above (every workgroup reduces one arg-max record per row tile: N / TR of them);
+// measured N = 4096: 25.1 / 26.3 / 28.3 ms for 8 / 16 / 32, N = 8192: 83.7 / 77.8 / 76.4 ms
 
 Blocked64Plan make_blocked64_plan(int n, int bw)
 {
@@ -44,7 +47,11 @@ Blocked64Plan make_blocked64_plan(int n, int bw)
     p.bw = bw;
     p.np = ((n + bw - 1) / bw) * bw;
     p.ld = p.np;
-    p.tr = (p.np <= 4096) ? 16 : 32;
+    p.tr = (p.np <= 4096) ? 8 : 32;
+    if (const char *e = std::getenv("MI32_B64_TR")) {  // experiments
+        const int v = std::atoi(e);
+        if (v == 8 || v == 16 || v == 32) p.tr = v;
+    }
     p.row_tiles = (p.np + p.tr - 1) / p.tr;
     return p;
 }
@@ -171,15 +178,15 @@ __global__ __launch_bounds__(kB64Threads) void b64_panel_step_kernel(
     PivotRec<double> k = PivotRec<double>::none();
     for (int t = tid; t < npart; t += kB64Threads) {
         const PivotRec<double> o = keys_in[(size_t)b * npart + t];
-        k = o.beats(k) ? o : k;
+        k = decltype(k)::best_of(o, k);
     }
     k = wave_max_rec<double>(k);
     if ((tid & 63) == 0) s_key[tid >> 6] = k;
     __syncthreads();
     {
-        const PivotRec<double> a = s_key[0].beats(s_key[1]) ? s_key[0] : s_key[1];
-        const PivotRec<double> c = s_key[2].beats(s_key[3]) ? s_key[2] : s_key[3];
-        k = a.beats(c) ? a : c;
+        const PivotRec<double> a = PivotRec<double>::best_of(s_key[0], s_key[1]);
+        const PivotRec<double> c = PivotRec<double>::best_of(s_key[2], s_key[3]);
+        k = decltype(k)::best_of(a, c);
     }
     const int p = k.row(r);
     const double piv = src[(size_t)p * ld + r];  // read before the swap, as mat_inv_32.cpp:70,129-130
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(kB64Threads) void b64_panel_step_kernel(
         if (has_next && i > r) {
             const double v = (nc == 0) ? o.x : (nc == 1) ? o.y : (nc == 2) ? o.z : o.w;
             const PivotRec<double> kk = PivotRec<double>::make(v, i);
-            best = kk.beats(best) ? kk : best;
+            best = decltype(best)::best_of(kk, best);
         }
     }
     // maxPivot record of column r + 1 for the next launch: the TY threads (one tx) that own that column hold
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(kB64Threads) void b64_panel_step_kernel(
     if (has_next && ty == 0) {
         PivotRec<double> m = s_part[0];
 #pragma unroll
-        for (int q = 1; q < TY; ++q) m = s_part[q].beats(m) ? s_part[q] : m;
+        for (int q = 1; q < TY; ++q) m = PivotRec<double>::best_of(s_part[q], m);
         keys_out[(size_t)b * npart + blockIdx.y] = m;
     }
     if (blockIdx.y == 0 && tid == 0) {
@@ -381,6 +388,9 @@ static void b64_launch_step(const dim3 &grid, hipStream_t stream, const double *
 {
     if (p.tr == 16)
         hipLaunchKernelGGL((b64_panel_step_kernel<TX, 16>), grid, dim3(kB64Threads), 0, stream, x, y, p.np, p.ld, wstride, r,
+                           col_lo, kin, kout, p.row_tiles, orig, rowmap, status);
+    else if (p.tr == 8)
+        hipLaunchKernelGGL((b64_panel_step_kernel<TX, 8>), grid, dim3(kB64Threads), 0, stream, x, y, p.np, p.ld, wstride, r,
                            col_lo, kin, kout, p.row_tiles, orig, rowmap, status);
     else
         hipLaunchKernelGGL((b64_panel_step_kernel<TX, 32>), grid, dim3(kB64Threads), 0, stream, x, y, p.np, p.ld, wstride, r,

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kSweepThreads) void sweep_init_kernel(const T *__re
             *reinterpret_cast<Vec4<T> *>(w + (size_t)i * ld + j4) = v;
             if (j4 == 0) {
                 const PivotRec<T> k = PivotRec<T>::make(v.x, i);
-                best = k.beats(best) ? k : best;
+                best = decltype(best)::best_of(k, best);
             }
         }
     }
@@ -177,15 +177,15 @@ __global__ __launch_bounds__(kSweepThreads) void gj_sweep_step_kernel(const T *_
         PivotRec<T> k = PivotRec<T>::none();
         for (int t = tid; t < npart; t += kSweepThreads) {
             const PivotRec<T> o = keys_in[(size_t)b * npart + t];
-            k = o.beats(k) ? o : k;
+            k = decltype(k)::best_of(o, k);
         }
         k = wave_max_rec<T>(k);
         if ((tid & 63) == 0) s_key[tid >> 6] = k;
         __syncthreads();
         {
-            const PivotRec<T> a = s_key[0].beats(s_key[1]) ? s_key[0] : s_key[1];
-            const PivotRec<T> c = s_key[2].beats(s_key[3]) ? s_key[2] : s_key[3];
-            k = a.beats(c) ? a : c;
+            const PivotRec<T> a = PivotRec<T>::best_of(s_key[0], s_key[1]);
+            const PivotRec<T> c = PivotRec<T>::best_of(s_key[2], s_key[3]);
+            k = decltype(k)::best_of(a, c);
         }
         p = k.row(r);
     }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kSweepThreads) void gj_sweep_step_kernel(const T *_
             *reinterpret_cast<Vec4<T> *>(dst + (size_t)i * ld + j4) = o;
             if (has_next && i > r) {
                 const PivotRec<T> kk = PivotRec<T>::make(comp<T>(o, nc), i);
-                best = kk.beats(best) ? kk : best;
+                best = decltype(best)::best_of(kk, best);
             }
         }
     }
