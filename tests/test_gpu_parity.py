@@ -793,3 +793,30 @@ def test_no_pivot_variant_bit_identical_to_oracle(oracle, n):
     finally:
         inv.close()
     assert g.matrix_inversion_no_pivots(a64.reshape(-1), n + 1).size == 0   # the shape guards
+
+
+def test_bench_py_contract_line():
+    """bench.py prints ONE JSON line with the driver's contract keys, the roofline and cpu_baseline objects and the
+    round-2 additions (e2e through matrix_inv_32, time-dominant kernel class, reference distributions), on a small run."""
+    import json
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "640", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "e2e"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f32" and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    assert abs(d["value"] - 1e3 * 1 / d["ms_per_step"]) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and rf["peak"] > 0 and 0 < rf["frac"] < 1 and "time_dominant" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert d["e2e"]["e2e_ms"] >= d["e2e"]["compute_ms_inside"] > 0 and d["speedup_vs_numpy_e2e"] > 0
+    assert d["residual_inf"] < 1e-3 and d["status_max"] == 0
+    assert set(d["residuals_reference_distributions"]) == {"D_ref100", "D_rand"}
