@@ -15,7 +15,7 @@ from ._lib import (  # noqa: F401
     Mi32Error,
     build_library,
 )
-from .api import Inverter, fp32_bench, just_inv, last_timing, matrix_inv_32, matrix_inv_32_batched, matrix_inv_64, matrix_inversion_no_pivots  # noqa: F401
+from .api import Inverter, fp32_bench, fp64_bench, just_inv, matrix_multiply, last_timing, matrix_inv_32, matrix_inv_32_batched, matrix_inv_64, matrix_inversion_no_pivots  # noqa: F401
 from .sharding import invert_distributed, invert_sharded, shard_range  # noqa: F401
 
 __all__ = [
@@ -25,6 +25,8 @@ __all__ = [
     "matrix_inversion_no_pivots",
     "just_inv",
     "fp32_bench",
+    "fp64_bench",
+    "matrix_multiply",
     "last_timing",
     "Inverter",
     "shard_range",

@@ -44,6 +44,8 @@ C_ABI_SYMBOLS = (
     "mi32_get_profile",
     "mi32_last_timing",
     "mi32_bench_32",
+    "mi32_bench_64",
+    "mi32_matrix_multiply_64",
     "mi32_resolve_algo",
     "mi32_matrix_inv_64",
     "mi32_matrix_inversion_no_pivots",
@@ -135,6 +137,12 @@ def load() -> ctypes.CDLL:
     lib.mi32_get_profile.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
     lib.mi32_bench_32.restype = ctypes.c_int
     lib.mi32_bench_32.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ctypes.POINTER(ctypes.c_double)]
+    lib.mi32_bench_64.restype = ctypes.c_int
+    lib.mi32_bench_64.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_size_t, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    lib.mi32_matrix_multiply_64.restype = ctypes.c_int
+    lib.mi32_matrix_multiply_64.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_size_t,
+                                            ctypes.POINTER(ctypes.c_double)]
     lib.mi32_last_timing.restype = ctypes.c_int
     lib.mi32_last_timing.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     lib.mi32_resolve_algo.restype = ctypes.c_int

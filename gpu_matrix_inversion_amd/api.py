@@ -135,6 +135,39 @@ def fp32_bench(matrix_vector, matrix_order: int):
     return out, dict(zip(_lib.TIMES10_SLOTS, (float(t) for t in times)))
 
 
+def fp64_bench(matrix_vector, matrix_order: int, pivoting: bool = True):
+    """``Res FP64_bench`` / ``Res no_pivots_bench`` of the reference (headers.h:14,16): ``(inverse float64, times)``."""
+    lib = _lib.load()
+    n = int(matrix_order)
+    v = np.ascontiguousarray(np.asarray(matrix_vector, dtype=np.float64).reshape(-1))
+    if n <= 0 or int(v.size // n) != n:
+        return np.empty(0, dtype=np.float64), {}
+    out = np.empty(n * n, dtype=np.float64)
+    times = (ctypes.c_double * 10)()
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib.mi32_bench_64(v.ctypes.data_as(dp), v.size, n, out.ctypes.data_as(dp), times, 1 if pivoting else 0)
+    if rc == _lib.MI32_RUNTIME_ERROR:
+        raise Mi32Error(lib.mi32_last_error().decode())
+    if rc != MI32_OK:
+        return np.empty(0, dtype=np.float64), {}
+    return out, dict(zip(_lib.TIMES10_SLOTS, (float(t) for t in times)))
+
+
+def matrix_multiply(matrice_a, matrice_b) -> float:
+    """The reference's verification helper ``matrix_multiply`` (matrix_multiply.cpp:15): ``sqrt(N) - ||A B||_F`` with the
+    product in double on the device; flat or square float64 operands of N*N entries each."""
+    lib = _lib.load()
+    a = np.ascontiguousarray(np.asarray(matrice_a, dtype=np.float64).reshape(-1))
+    b = np.ascontiguousarray(np.asarray(matrice_b, dtype=np.float64).reshape(-1))
+    if a.size != b.size:
+        raise ValueError("operands of different size")
+    err = ctypes.c_double()
+    dp = ctypes.POINTER(ctypes.c_double)
+    _lib.check(lib.mi32_matrix_multiply_64(a.ctypes.data_as(dp), b.ctypes.data_as(dp), a.size, ctypes.byref(err)),
+               "mi32_matrix_multiply_64")
+    return err.value
+
+
 def last_timing():
     """(total_seconds, compute_seconds) of the last host-pointer call: the two numbers the
     reference prints (mat_inv_32.cpp:385-386)."""

@@ -713,6 +713,29 @@ static int host_copy(mi32_context *h, void *dev, void *host, size_t bytes, bool 
     return MI32_OK;
 }
 
+// The reference's ten timing slots (FP32_bench.cpp:256-443) from the profiler's per-class milliseconds and the host
+// clock stamps of a host-pointer call (tq0: before the context, t0: after it, t1: H2D done, t2: compute done, t3: D2H done).
+static void fill_times10(double *times10, const double *ms, std::chrono::steady_clock::time_point tq0,
+                         std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point t1,
+                         std::chrono::steady_clock::time_point t2, std::chrono::steady_clock::time_point t3)
+{
+    auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double>(b - a).count();
+    };
+    times10[0] = sec(tq0, t0);
+    times10[1] = sec(t0, t1);
+    times10[2] = 0.0;  // one ahead-of-time compiled code object: nothing is built at run time
+    times10[3] = ms[KC_INIT] * 1e-3;
+    // the panel kernel IS maxPivot + finalMaxPivot + pivotElements + fixRow (+ fixColumn on the panel's own columns); the
+    // fused step launches of the sweep path are accounted to the column slot, where the reference spends its time
+    times10[4] = ms[KC_PANEL] * 1e-3;
+    times10[5] = 0.0;  // fixRow has no launch of its own
+    times10[6] = (ms[KC_SWEEP_STEP] + ms[KC_UPDATE_IN] + ms[KC_UPDATE_OUT] + ms[KC_TRANSPOSE]) * 1e-3;
+    times10[7] = sec(t1, t2);
+    times10[8] = ms[KC_FINISH] * 1e-3 + sec(t2, t3);
+    times10[9] = sec(tq0, t3);
+}
+
 // The host-pointer path.  times10 (may be NULL): the reference's timing vector, FP32_bench.cpp:256-443 /
 // res_struct.h:4-6 -- [0] queue/context, [1] buffers (+ the H2D copy the reference's CL_MEM_COPY_HOST_PTR does),
 // [2] program build, [3] makeAugmented, [4] pivot, [5] row, [6] column, [7] compute, [8] getInverted (+ D2H),
@@ -758,19 +781,7 @@ static int host_invert_32(const float *a, int n, int batch, float *inv, int *sta
         rc = mi32_get_profile(h, ms, cnt, KC_COUNT);
         (void)mi32_set_profiling(h, 0);
         if (rc != MI32_OK) return rc;
-        times10[0] = std::chrono::duration<double>(t0 - tq0).count();
-        times10[1] = std::chrono::duration<double>(t1 - t0).count();
-        times10[2] = 0.0;  // one ahead-of-time compiled code object: nothing is built at run time
-        times10[3] = ms[KC_INIT] * 1e-3;
-        // the panel kernel IS maxPivot + finalMaxPivot + pivotElements + fixRow (+ fixColumn on the panel's own
-        // columns); the sweep path's one fused launch per step is accounted to the column slot, where the
-        // reference spends its time (fixColumnKernel)
-        times10[4] = ms[KC_PANEL] * 1e-3;
-        times10[5] = 0.0;  // fixRow has no launch of its own
-        times10[6] = (ms[KC_SWEEP_STEP] + ms[KC_UPDATE_IN] + ms[KC_UPDATE_OUT] + ms[KC_TRANSPOSE]) * 1e-3;
-        times10[7] = g_last_compute;
-        times10[8] = ms[KC_FINISH] * 1e-3 + std::chrono::duration<double>(t3 - t2).count();
-        times10[9] = std::chrono::duration<double>(t3 - tq0).count();
+        fill_times10(times10, ms, tq0, t0, t1, t2, t3);
     }
     int worst = MI32_OK;
     for (int b = 0; b < batch; ++b) {
@@ -809,24 +820,33 @@ int mi32_matrix_inv_32(const float *a_rowmajor, size_t a_len, int n, float *inv_
     return mi32_matrix_inv_32_batched(a_rowmajor, n, 1, inv_rowmajor, nullptr);
 }
 
-static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor, bool pivoting);
+static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor, bool pivoting,
+                          double *times10);
 
 int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor)
 {
-    return host_invert_64(a_rowmajor, a_len, n, inv_rowmajor, true);
+    return host_invert_64(a_rowmajor, a_len, n, inv_rowmajor, true, nullptr);
 }
 
 int mi32_matrix_inversion_no_pivots(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor)
 {
-    return host_invert_64(a_rowmajor, a_len, n, inv_rowmajor, false);
+    return host_invert_64(a_rowmajor, a_len, n, inv_rowmajor, false, nullptr);
 }
 
-static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor, bool pivoting)
+int mi32_bench_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor, double *times10, int pivoting)
+{
+    if (!times10) return MI32_BAD_SHAPE;
+    return host_invert_64(a_rowmajor, a_len, n, inv_rowmajor, pivoting != 0, times10);
+}
+
+static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor, bool pivoting,
+                          double *times10)
 {
     // the guards of the fp32 library (mat_inv_32.cpp:206-215); matrix_inversion_FP64.cpp has the same two
     if (n <= 0) return MI32_BAD_SHAPE;
     if ((int)(a_len / (size_t)n) != n) return MI32_BAD_SHAPE;
     if (!a_rowmajor || !inv_rowmajor) return MI32_BAD_SHAPE;
+    const auto tq0 = std::chrono::steady_clock::now();
     mi32_context *h = nullptr;
     int rc = default_context(&h);
     if (rc != MI32_OK) return rc;
@@ -836,6 +856,12 @@ static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double 
     const size_t elems = (size_t)n * n;
     rc = ensure_io(h, 2 * elems, 1);  // doubles: two 4-byte units each
     if (rc != MI32_OK) return rc;
+    if (times10) {
+        rc = mi32_set_profiling(h, 1);
+        if (rc != MI32_OK) return rc;
+        double ms0[KC_COUNT]; long long cnt0[KC_COUNT];
+        (void)mi32_get_profile(h, ms0, cnt0, KC_COUNT);  // drop what an earlier call left
+    }
     double *din = reinterpret_cast<double *>(h->d_in), *dout = reinterpret_cast<double *>(h->d_out);
     rc = host_copy(h, din, const_cast<double *>(a_rowmajor), elems * sizeof(double), true);
     if (rc != MI32_OK) return rc;
@@ -857,7 +883,46 @@ static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double 
     const auto t3 = std::chrono::steady_clock::now();
     g_last_total = std::chrono::duration<double>(t3 - t0).count();
     g_last_compute = std::chrono::duration<double>(t2 - t1).count();
+    if (times10) {
+        double ms[KC_COUNT]; long long cnt[KC_COUNT];
+        rc = mi32_get_profile(h, ms, cnt, KC_COUNT);
+        (void)mi32_set_profiling(h, 0);
+        if (rc != MI32_OK) return rc;
+        fill_times10(times10, ms, tq0, t0, t1, t2, t3);
+    }
     return st;
+}
+
+// matrix_multiply of the reference (matrix_multiply.cpp:15-212): C = A * B in double on the device, returns
+// sqrt(N) - ||C||_F -- the scalar the experiment driver writes per size (main_file.cpp:80-81).
+int mi32_matrix_multiply_64(const double *a, const double *b, size_t len, double *errore)
+{
+    if (!a || !b || !errore || len == 0) return MI32_BAD_SHAPE;
+    const int n = (int)std::llround(std::sqrt((double)len));  // the reference takes the order as sqrt(size), :44
+    if (n <= 0 || (size_t)n * n != len) return MI32_BAD_SHAPE;
+    mi32_context *h = nullptr;
+    int rc = default_context(&h);
+    if (rc != MI32_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_host_call_mu);
+    MI32_HIP(hipSetDevice(h->device));
+    rc = ensure_io(h, 2 * len, 1);
+    if (rc != MI32_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lk2(h->mu);
+        rc = ensure_ws(h, residual_workspace_bytes(n, 1) + 64);
+    }
+    if (rc != MI32_OK) return rc;
+    double *da = reinterpret_cast<double *>(h->d_in), *db = reinterpret_cast<double *>(h->d_out);
+    rc = host_copy(h, da, const_cast<double *>(a), len * sizeof(double), true);
+    if (rc != MI32_OK) return rc;
+    rc = host_copy(h, db, const_cast<double *>(b), len * sizeof(double), true);
+    if (rc != MI32_OK) return rc;
+    double *d_out = reinterpret_cast<double *>((char *)h->ws + residual_workspace_bytes(n, 1));
+    hipError_t e = frobenius_launch_f64(da, db, n, d_out, h->ws, h->stream);
+    if (e != hipSuccess) return fail(e, "matrix_multiply launch");
+    MI32_HIP(hipMemcpyAsync(errore, d_out, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MI32_HIP(hipStreamSynchronize(h->stream));
+    return MI32_OK;
 }
 
 int mi32_last_timing(double *total_seconds, double *compute_seconds)
@@ -913,6 +978,47 @@ Res FP32_bench(std::vector<float> matrix_vector, int matrix_order)
     res.inversa32 = std::move(inv);
     res.times = std::move(times);
     return res;
+}
+
+Res FP64_bench(std::vector<double> matrix_vector, int matrix_order)
+{
+    Res res;
+    if (matrix_order <= 0) return res;
+    if ((int)(matrix_vector.size() / (size_t)matrix_order) != matrix_order) return res;
+    std::vector<double> inv((size_t)matrix_order * matrix_order, 0.0), times(10, 0.0);
+    if (mi32_bench_64(matrix_vector.data(), matrix_vector.size(), matrix_order, inv.data(), times.data(), 1) != MI32_OK) return res;
+    res.inversa64 = std::move(inv);
+    res.times = std::move(times);
+    return res;
+}
+
+Res no_pivots_bench(std::vector<double> matrix_vector, int matrix_order)
+{
+    Res res;
+    if (matrix_order <= 0) return res;
+    if ((int)(matrix_vector.size() / (size_t)matrix_order) != matrix_order) return res;
+    std::vector<double> inv((size_t)matrix_order * matrix_order, 0.0), times(10, 0.0);
+    if (mi32_bench_64(matrix_vector.data(), matrix_vector.size(), matrix_order, inv.data(), times.data(), 0) != MI32_OK) return res;
+    res.inversa64 = std::move(inv);
+    res.times = std::move(times);
+    return res;
+}
+
+// the experiment twin of matrix_inv_32 (headers.h:7, matrix_inversion_FP32.cpp:11): same call shape; {} for an
+// invalid matrix (its exact-identity check of the reduced left half, :814-835)
+std::vector<float> matrix_inversion_FP32(std::vector<float> matrix_vector, int matrix_order)
+{
+    return matrix_inv_32(static_cast<std::vector<float> &&>(matrix_vector), matrix_order);
+}
+
+// headers.h:5, matrix_multiply.cpp:15: sqrt(N) - ||A * B||_F, N = sqrt(size)
+double matrix_multiply(std::vector<double> matriceA, std::vector<double> matriceB)
+{
+    double errore = std::nan("");
+    if (matriceA.size() != matriceB.size()) return errore;
+    const int rc = mi32_matrix_multiply_64(matriceA.data(), matriceB.data(), matriceA.size(), &errore);
+    if (rc == MI32_RUNTIME_ERROR) std::fprintf(stderr, "matrix_multiply: %s\n", mi32_last_error());
+    return errore;
 }
 
 // ---- the reference's fp64 entry point, unchanged signature (matrix_inversion/headers.h:9) ----

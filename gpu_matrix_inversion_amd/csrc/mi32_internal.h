@@ -129,5 +129,6 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
 hipError_t residual_launch(const float *d_a, const float *d_x, int n, int batch, double *d_out, void *ws,
                            hipStream_t stream);
 size_t residual_workspace_bytes(int n, int batch);
+hipError_t frobenius_launch_f64(const double *d_a, const double *d_b, int n, double *d_out, void *ws, hipStream_t stream);
 
 }  // namespace mi32

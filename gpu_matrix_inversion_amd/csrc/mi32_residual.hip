@@ -20,17 +20,19 @@ size_t residual_workspace_bytes(int n, int batch) { return align256(((size_t)2 *
 // lane & 15]); the fp32 operands are widened to fp64 on their way from LDS, so every product is exact and every
 // element is one k-ascending fp64 fma chain.
 // which = 0: right residual (L=A, R=X) also accumulates sum of squares of C.
+// TIN = float: the inverse check of the fp32 path.  TIN = double: matrix_multiply of the reference (fp64 operands).
 typedef double res_d4v __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void residual_tile_kernel(const float *__restrict__ l_all,
-                                                             const float *__restrict__ r_all, int n,
+template <typename TIN>
+__global__ __launch_bounds__(256) void residual_tile_kernel(const TIN *__restrict__ l_all,
+                                                             const TIN *__restrict__ r_all, int n,
                                                              double *__restrict__ ws, int which)
 {
-    __shared__ float s_l[16][65];  // [k][i]
-    __shared__ float s_r[16][65];  // [k][j]
+    __shared__ TIN s_l[16][65];  // [k][i]
+    __shared__ TIN s_r[16][65];  // [k][j]
     __shared__ double s_sq[4];
     const int b = blockIdx.z;
-    const float *L = l_all + (size_t)b * n * n;
-    const float *R = r_all + (size_t)b * n * n;
+    const TIN *L = l_all + (size_t)b * n * n;
+    const TIN *R = r_all + (size_t)b * n * n;
     double *rowsum = ws + (size_t)b * (2 * (size_t)n + 2) + (which ? n : 0);
     double *sumsq = ws + (size_t)b * (2 * (size_t)n + 2) + 2 * (size_t)n;
     const int tid = threadIdx.x;
@@ -47,26 +49,26 @@ __global__ __launch_bounds__(256) void residual_tile_kernel(const float *__restr
             for (int q = 0; q < 4; ++q) acc[u][v][q] = 0.0;
 
     for (int k0 = 0; k0 < n; k0 += 16) {
-        if ((n & 3) == 0) {  // rows are 16-byte aligned: one 16-byte load per thread and operand
-            typedef float res_f4v __attribute__((ext_vector_type(4)));
+        if ((n & 3) == 0) {  // rows are 16-byte aligned: one 16- (32-) byte load per thread and operand
+            typedef TIN res_f4v __attribute__((ext_vector_type(4)));
             const int ii = tid >> 2, k4 = (tid & 3) * 4;   // L tile: 64 rows x 16 k
-            res_f4v v = (res_f4v)(0.0f);
+            res_f4v v = (res_f4v)(TIN(0));
             if (i0 + ii < n && k0 + k4 < n) v = *reinterpret_cast<const res_f4v *>(L + (size_t)(i0 + ii) * n + k0 + k4);
             s_l[k4 + 0][ii] = v[0]; s_l[k4 + 1][ii] = v[1]; s_l[k4 + 2][ii] = v[2]; s_l[k4 + 3][ii] = v[3];
             const int kk = tid >> 4, j4 = (tid & 15) * 4;   // R tile: 16 k x 64 j
-            res_f4v w = (res_f4v)(0.0f);
+            res_f4v w = (res_f4v)(TIN(0));
             if (k0 + kk < n && j0 + j4 < n) w = *reinterpret_cast<const res_f4v *>(R + (size_t)(k0 + kk) * n + j0 + j4);
             s_r[kk][j4 + 0] = w[0]; s_r[kk][j4 + 1] = w[1]; s_r[kk][j4 + 2] = w[2]; s_r[kk][j4 + 3] = w[3];
         } else {
             for (int idx = tid; idx < 64 * 16; idx += 256) {   // L tile: 64 rows x 16 k
                 const int ii = idx >> 4, kk = idx & 15;
                 const int gi = i0 + ii, gk = k0 + kk;
-                s_l[kk][ii] = (gi < n && gk < n) ? L[(size_t)gi * n + gk] : 0.0f;
+                s_l[kk][ii] = (gi < n && gk < n) ? L[(size_t)gi * n + gk] : TIN(0);
             }
             for (int idx = tid; idx < 16 * 64; idx += 256) {
                 const int kk = idx >> 6, jj = idx & 63;
                 const int gk = k0 + kk, gj = j0 + jj;
-                s_r[kk][jj] = (gk < n && gj < n) ? R[(size_t)gk * n + gj] : 0.0f;
+                s_r[kk][jj] = (gk < n && gj < n) ? R[(size_t)gk * n + gj] : TIN(0);
             }
         }
         __syncthreads();
@@ -155,9 +157,25 @@ hipError_t residual_launch(const float *d_a, const float *d_x, int n, int batch,
     hipError_t e = hipMemsetAsync(ws, 0, ((size_t)2 * n + 2) * sizeof(double) * batch, stream);
     if (e != hipSuccess) return e;
     const dim3 grid((n + 63) / 64, (n + 63) / 64, batch);
-    hipLaunchKernelGGL(residual_tile_kernel, grid, dim3(256), 0, stream, d_a, d_x, n, (double *)ws, 0);
-    hipLaunchKernelGGL(residual_tile_kernel, grid, dim3(256), 0, stream, d_x, d_a, n, (double *)ws, 1);
+    hipLaunchKernelGGL(residual_tile_kernel<float>, grid, dim3(256), 0, stream, d_a, d_x, n, (double *)ws, 0);
+    hipLaunchKernelGGL(residual_tile_kernel<float>, grid, dim3(256), 0, stream, d_x, d_a, n, (double *)ws, 1);
     hipLaunchKernelGGL(residual_finalize_kernel, dim3(batch), dim3(256), 0, stream, (const double *)ws, n, d_out);
+    return hipGetLastError();
+}
+
+// sqrt(N) - ||A B||_F for fp64 operands (matrix_multiply.cpp:17-36 the product, :193-200 the metric): one product,
+// d_out[0] = the metric.  ws: residual_workspace_bytes(n, 1).
+__global__ void frobenius_finalize_kernel(const double *__restrict__ ws, int n, double *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = sqrt((double)n) - sqrt(ws[2 * (size_t)n]);
+}
+hipError_t frobenius_launch_f64(const double *d_a, const double *d_b, int n, double *d_out, void *ws, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(ws, 0, ((size_t)2 * n + 2) * sizeof(double), stream);
+    if (e != hipSuccess) return e;
+    const dim3 grid((n + 63) / 64, (n + 63) / 64, 1);
+    hipLaunchKernelGGL(residual_tile_kernel<double>, grid, dim3(256), 0, stream, d_a, d_b, n, (double *)ws, 0);
+    hipLaunchKernelGGL(frobenius_finalize_kernel, dim3(1), dim3(64), 0, stream, (const double *)ws, n, d_out);
     return hipGetLastError();
 }
 

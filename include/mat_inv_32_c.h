@@ -134,6 +134,11 @@ int mi32_get_profile(mi32_handle_t h, double *ms_per_class, long long *launches_
  *   [7] compute (wall time of the device-resident inversion)   [8] getInverted = un-permutation kernels + D2H
  *   [9] total.  Slots 3-6 and the kernel part of 8 are HIP-event durations on the launch stream. */
 int mi32_bench_32(const float *a_rowmajor, size_t a_len, int n, float *inv_rowmajor, double *times10);
+/* the fp64 twins (Res FP64_bench / no_pivots_bench, headers.h:14,16): pivoting = 0 selects the no-pivot variant */
+int mi32_bench_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor, double *times10, int pivoting);
+/* matrix_multiply of the reference (matrix_multiply.cpp:15): *errore = sqrt(N) - ||A * B||_F, N = sqrt(len), the product
+ * accumulated in double on the fp64 matrix cores; MI32_BAD_SHAPE unless len is a perfect square */
+int mi32_matrix_multiply_64(const double *a, const double *b, size_t len, double *errore);
 
 /* ---- introspection -------------------------------------------------------- */
 /* The two durations the reference prints per call ("Tempo Totale Impiegato",

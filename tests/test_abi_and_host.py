@@ -56,6 +56,16 @@ def test_every_declared_symbol_is_exported():
     assert out == "FP32_bench(std::vector<float, std::allocator<float> >, int)"
     hb = open(os.path.join(ROOT, "include", "mat_inv_bench.h")).read()
     assert "Res FP32_bench(std::vector<float> matrix_vector, int matrix_order);" in hb
+    # ... and the rest of the experiment project's header, declaration for declaration (headers.h:5-16)
+    for decl, mangled in (
+            ("double matrix_multiply(std::vector<double> matriceA, std::vector<double> matriceB);",
+             "_Z15matrix_multiplySt6vectorIdSaIdEES1_"),
+            ("std::vector<float> matrix_inversion_FP32(std::vector<float> matrix_vector, int matrix_order);",
+             "_Z21matrix_inversion_FP32St6vectorIfSaIfEEi"),
+            ("Res no_pivots_bench(std::vector<double> matrix_vector, int matrix_order);", "_Z15no_pivots_benchSt6vectorIdSaIdEEi"),
+            ("Res FP64_bench(std::vector<double> matrix_vector, int matrix_order);", "_Z10FP64_benchSt6vectorIdSaIdEEi")):
+        assert decl in hb, decl
+        assert getattr(lib, mangled) is not None, mangled
     assert re.search(r"struct Res \{\s*std::vector<double> inversa64;\s*std::vector<double> times;\s*"
                      r"std::vector<float> inversa32;\s*\};", hb)
 

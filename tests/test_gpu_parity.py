@@ -820,3 +820,49 @@ def test_bench_py_contract_line():
     assert d["e2e"]["e2e_ms"] >= d["e2e"]["compute_ms_inside"] > 0 and d["speedup_vs_numpy_e2e"] > 0
     assert d["residual_inf"] < 1e-3 and d["status_max"] == 0
     assert set(d["residuals_reference_distributions"]) == {"D_ref100", "D_rand"}
+
+
+def test_experiment_header_twins(oracle, tmp_path):
+    """The rest of the reference's experiment header (headers.h:5-16) on the HIP path: FP64_bench / no_pivots_bench
+    (Res.inversa64 + the ten timing slots), matrix_inversion_FP32 (the experiment twin of matrix_inv_32) and the
+    verification helper matrix_multiply (sqrt(N) - ||A B||_F, product in double), through Python and through a C++
+    caller of include/mat_inv_bench.h."""
+    n = 300
+    a = dist_matrix("gate", n, 77).astype(np.float64)
+    x, t = g.fp64_bench(a.reshape(-1), n)
+    assert np.array_equal(x, g.matrix_inv_64(a.reshape(-1), n)) and list(t) == list(_lib.TIMES10_SLOTS)
+    assert t["pivot"] > 0 and t["column"] > 0 and t["compute"] < t["total"]          # blocked fp64: panel steps + rank-bw updates
+    dom = np.abs(a) + np.diag(np.abs(a).sum(axis=1) + 1.0)
+    y, t2 = g.fp64_bench(dom.reshape(-1), n, pivoting=False)
+    assert np.array_equal(y, oracle.matrix_inversion_no_pivots(dom, n)) and t2["pivot"] == 0.0 and t2["column"] > 0
+    # matrix_multiply: the reference's acceptance metric on (inverse, matrix), against numpy in float64
+    err = g.matrix_multiply(x, a)
+    want = np.sqrt(n) - np.linalg.norm(x.reshape(n, n) @ a, "fro")
+    assert abs(err - want) <= 1e-9 and abs(err) < 1e-9
+    r = np.random.default_rng(5)
+    p_, q_ = r.normal(size=(n, n)), r.normal(size=(n, n))
+    assert g.matrix_multiply(p_, q_) == pytest.approx(np.sqrt(n) - np.linalg.norm(p_ @ q_, "fro"), rel=1e-12)
+    with pytest.raises(ValueError):
+        g.matrix_multiply(np.ones(10), np.ones(10))          # 10 is not a perfect square
+    src = tmp_path / "exp_caller.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "mat_inv_bench.h"
+int main() {
+    std::vector<double> a = {2, 1, 0,  1, 3, 1,  0, 1, 4};
+    Res r = FP64_bench(a, 3), q = no_pivots_bench(a, 3);
+    std::vector<float> f = matrix_inversion_FP32(std::vector<float>(a.begin(), a.end()), 3);
+    std::printf("%zu %zu %zu %zu %zu\n", r.inversa64.size(), r.times.size(), q.inversa64.size(), q.times.size(), f.size());
+    std::printf("%.3e\n", matrix_multiply(r.inversa64, a));
+    std::printf("%zu\n", matrix_inversion_FP32(std::vector<float>(16, 1.0f), 4).size());
+    return 0;
+}
+''')
+    exe = tmp_path / "exp_caller"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lmat_inv_32", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "9 10 9 10 9" and abs(float(lines[1])) < 1e-12 and lines[2] == "0"
