@@ -19,7 +19,7 @@ import torch  # noqa: E402
 
 from gpu_matrix_inversion_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "gpu_matrix_inversion_amd", "lib", "libmat_inv_32_stamps.so")
+_lib.LIB_PATH = os.environ.get("MI32_STAMPS_LIB") or os.path.join(ROOT, "gpu_matrix_inversion_amd", "lib", "libmat_inv_32_stamps.so")
 import gpu_matrix_inversion_amd as g  # noqa: E402
 
 
