@@ -121,7 +121,7 @@ BlockedPlan make_blocked_plan(int n, int w, int bw, int batch)
     p.nthreads_panel = nt;
     p.rpt = rpt;
     // Multi-workgroup panels need every workgroup of a panel resident at once and a whole CU each; with the
-    // look-ahead kernel holding all but 32 CUs that is safe for a few matrices (MI32_MULTI_PANEL=0 turns it off).
+    // look-ahead kernel holding all but 16 (32 below 8192 rows) CUs that is safe for a few matrices (MI32_MULTI_PANEL=0 turns it off).
     p.multi_panel = (nt == 1024 && p.np > kPanelGroupRows && batch * kMaxPanelGroups <= 16) ? 1 : 0;
     if (const char *e = std::getenv("MI32_MULTI_PANEL")) p.multi_panel = p.multi_panel && std::atoi(e) != 0;
     if (w <= 0) w = 16;  // 32 is selectable where it fits, but measured slower (4.6 vs 4.2 ms at 2048^2)

@@ -223,6 +223,7 @@ struct mi32_context {
     hipStream_t split_stream = nullptr; // second half of a split batch (same priority as the main stream)
     hipEvent_t la_events[8] = {};
     int aux_workgroups = 0;
+    int aux_workgroups_large = 0;  // ... for matrices of 8192 rows and more
     bool lookahead = true;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -389,6 +390,13 @@ int mi32_create(mi32_handle_t *out, int device)
         if (reserve < 1) reserve = 1;
         if (reserve > prop.multiProcessorCount / 2) reserve = prop.multiProcessorCount / 2;
         h->aux_workgroups = prop.multiProcessorCount - reserve;
+        // From 8192 rows on every block waits for its look-ahead half, not for the panels: 16 free CUs are enough for
+        // the (up to 4) panel workgroups, and the half gets the other 16 (measured 16384^2: 111.4 -> 107.6 ms,
+        // 8192^2: 30.0 -> 29.7 ms; at 4096^2 the in-block updates want the free CUs: 8.82 -> 9.11 ms; 5 free CUs
+        // starve the shared panels: 137.7 ms).
+        h->aux_workgroups_large = env_int("MI32_RESERVED_CUS", 0) > 0 ? h->aux_workgroups
+                                                                    : prop.multiProcessorCount - 16;
+        if (h->aux_workgroups_large < h->aux_workgroups) h->aux_workgroups_large = h->aux_workgroups;
         int prio_low = 0, prio_high = 0;
         MI32_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         MI32_HIP(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_low));
@@ -547,7 +555,7 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
         ex.aux = h->lookahead ? h->aux_stream : nullptr;
         ex.events = h->la_events;
         ex.n_events = h->aux_stream ? 8 : 0;
-        ex.aux_workgroups = h->aux_workgroups;
+        ex.aux_workgroups = (n >= 8192) ? h->aux_workgroups_large : h->aux_workgroups;
         ex.prof = h->prof;
         const BlockedPlan p = plan_blocked(h, n, batch);
         if (!split_batch(h, algo, n, batch)) {
