@@ -64,8 +64,13 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 #ifndef MI32_BW_BK
 #define MI32_BW_BK 16
 #endif
+#ifndef MI32_BW_PF
+#define MI32_BW_PF 1   // the old values of a tile are fetched under the last k-tiles (mi32_rank_bw.h); the full-chip
+                       // kernel only: 4096^2 88.9 -> 86.6 us per launch, 64 x 2048^2 740 -> 704 us; the one-per-CU
+                       // look-ahead flavour loses with it (16384^2 110.9 -> 115.4 ms)
+#endif
 #ifndef MI32_BW_WPS
-#define MI32_BW_WPS 3
+#define MI32_BW_WPS (MI32_BW_PF ? 2 : 3)   // the prefetch keeps 64 more registers live: two workgroups per CU
 #endif
 static constexpr int kMaxBW = 512;  // widest outer block (rows of the transposed panel Gk)
 
@@ -1292,7 +1297,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
         (void)hipGetDevice(&dev);
         bool &attr_set = attr_set_dev[dev & 63];
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS>,
+            (void)hipFuncSetAttribute((const void *)gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS, 128, (MI32_BW_PF != 0)>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)rank_bw2_lds_bytes<MI32_BW_BK>(kMaxBW));
             (void)hipFuncSetAttribute((const void *)gj_rank_bw2_persistent_kernel<MI32_BW_BK>,
@@ -1438,7 +1443,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 pending_b = true;
             } else {
                 ProfScope ps(prof, KC_UPDATE_OUT, stream);
-                hipLaunchKernelGGL((gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS>), dim3((np / 128) * (np / 128), batch),
+                hipLaunchKernelGGL((gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS, 128, (MI32_BW_PF != 0)>), dim3((np / 128) * (np / 128), batch),
                                    dim3(256), rank_bw2_lds_bytes<MI32_BW_BK>(kb), stream, cur, oth, x, ws.mstride, ws.gk,
                                    ws.gkstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, exn, ws.tstride, 0, 0, guard);
             }

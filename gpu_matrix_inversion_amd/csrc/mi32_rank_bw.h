@@ -19,6 +19,8 @@
 //    front of every B load that all co-resident workgroups hit in lock-step.
 #pragma once
 #include "mi32_internal.h"
+#include <type_traits>
+#include <utility>
 
 namespace mi32 {
 
@@ -123,9 +125,27 @@ __device__ unsigned long long *g_rb_stamps;  // [workgroup][8]
 #define MI32_RB_STAMP(slot_) do { } while (0)
 #endif
 
+// The peeled tail of the k-loop with the old values' prefetch: k-tile pf0 + i issues chunk i (i < NCH) and every
+// k-tile that follows one lets that chunk stay in flight; the last two k-tiles issue nothing.
+template <int NCH, typename F, int... Is>
+__device__ __forceinline__ void rank_bw2_tail_impl(F &k_tile, int pf0, std::integer_sequence<int, Is...>)
+{
+    (k_tile(pf0 + Is, std::integral_constant<bool, (Is >= 1 && Is <= NCH)>{},
+            std::integral_constant<int, (Is < NCH ? Is : -1)>{}), ...);
+}
+template <int NCH, typename F>
+__device__ __forceinline__ void rank_bw2_tail(F &k_tile, int pf0)
+{
+    rank_bw2_tail_impl<NCH>(k_tile, pf0, std::make_integer_sequence<int, NCH + 2>{});
+}
+
 // One 128 x BN output tile (rt, ct) of matrix b (BN = 128 or 64: 4 waves as 2 x 2, 64 x BN/2 each).
 // rb_smem: rank_bw2_lds_bytes<BK, BN>(kdim) bytes of LDS.
-template <int BK, int BN = 128>
+// PF: the old values C of the tile are fetched DURING the k-loop, one 32 x 32 sub-tile (16 loads per lane) per
+// k-tile over the last k-tiles but two, instead of after it: at the sizes where every workgroup of the chip reaches
+// its epilogue at the same moment the reads then travel while the matrix pipe works.  A wave's loads complete in
+// order, so the wait in front of a k-tile lets exactly the youngest chunk stay in flight (vmcnt(16)).
+template <int BK, int BN = 128, bool PF = false>
 __device__ __forceinline__ void rank_bw2_tile(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
     const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
@@ -199,15 +219,44 @@ __device__ __forceinline__ void rank_bw2_tile(
     const int lhalf = lane >> 5;
     const int nk = kdim / BK;
     const bool tile_in_block = (row0 >= c0 && row0 < c0 + kdim);
+    constexpr int NCH = 2 * TN;                     // chunks of old values: one 32 x 32 sub-tile each
+    const bool pf = PF && nk >= NCH + 2;            // chunk c is issued in k-tile pf0 + c, the last one two k-tiles early
+    const int pf0 = nk - 2 - NCH;
+    float cv[2][TN][16];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) cv[tm][tn][reg] = 0.0f;
     MI32_RB_STAMP(1);
     MI32_RB_ISSUE(0, 0)
-    for (int t = 0; t < nk; ++t) {
+    // One k-tile.  WAIT16: the chunk of old values issued in the previous k-tile may stay in flight (everything older,
+    // this k-tile's operands included, has landed).  CH >= 0: this k-tile issues chunk CH, after its DMAs.
+    auto k_tile = [&](int t, auto WAIT16, auto CHUNK) {
+        constexpr bool wait16 = decltype(WAIT16)::value;
+        constexpr int ch = decltype(CHUNK)::value;
         const int buf = t & 1;
         // stage t has landed for this wave's DMAs; after the barrier for everyone's, and every wave is done
         // reading the other buffer (k-tile t-1), which the next DMA overwrites
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wait16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (t + 1 < nk) { MI32_RB_ISSUE(buf ^ 1, (t + 1) * BK) }
+        if constexpr (ch >= 0) {
+            // the chunk must be YOUNGER than the DMAs above (the partial wait counts on it), and loads from a
+            // restrict-const pointer are invariant to the compiler -- it would hoist them over anything: their
+            // address goes through a register only this asm statement defines
+            int pin = 0;
+            asm volatile("" : "+v"(pin));
+            constexpr int tm = ch / TN, tn = ch % TN;
+            const int col = col0 + wc * (BN / 2) + tn * 32 + lcol + pin;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                cv[tm][tn][reg] = src[(size_t)s_map[lr] * ld + col];
+            }
+        }
         const float *pa = s_a + buf * BK * 128 + lhalf * 128 + wr * 64 + lcol;
         const float *pb = s_b + buf * BK * BN + lhalf * BN + wc * (BN / 2) + lcol;
         float af[2], bf[TN];
@@ -233,6 +282,17 @@ __device__ __forceinline__ void rank_bw2_tile(
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) bf[tn] = bfn[tn];
         }
+    };
+    typedef std::integral_constant<int, -1> NoChunk;
+    if (pf && !tile_in_block) {
+        // the last NCH + 2 k-tiles are peeled off the loop: straight-line code, where hipcc knows that nothing is
+        // pending on the registers a chunk is loaded into (inside a loop it waits for vmcnt(0) in front of each)
+        for (int t = 0; t < pf0; ++t) k_tile(t, std::false_type{}, NoChunk{});
+        if constexpr (PF) {
+            rank_bw2_tail<NCH>(k_tile, pf0);
+        }
+    } else {
+        for (int t = 0; t < nk; ++t) k_tile(t, std::false_type{}, NoChunk{});
     }
 #undef MI32_RB_ISSUE
     MI32_RB_STAMP(2);
@@ -244,27 +304,25 @@ __device__ __forceinline__ void rank_bw2_tile(
             const int col = col0 + wc * (BN / 2) + tn * 32 + lcol;
             // the old values C (row-mapped); the rows of the block itself start from 0.  Block bounds are
             // multiples of 128, so a whole tile is either inside the block or outside it.
-            float cv[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) cv[reg] = 0.0f;
-            if (!tile_in_block) {
+            float(&cq)[16] = cv[tm][tn];
+            if (!tile_in_block && !pf) {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                    cv[reg] = src[(size_t)s_map[lr] * ld + col];
+                    cq[reg] = src[(size_t)s_map[lr] * ld + col];
                 }
             }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int grow = row0 + wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                cv[reg] += acc[tm][tn][reg];
-                dst[(size_t)grow * ld + col] = cv[reg];
+                cq[reg] += acc[tm][tn][reg];
+                dst[(size_t)grow * ld + col] = cq[reg];
             }
             // the next block's first sub-panels, compact and transposed: registers 4q .. 4q+3 are 4 consecutive rows
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                panel_export_store4(ex, tstride, b, np, col, row0 + wr * 64 + tm * 32 + 8 * q + 4 * lhalf, cv[4 * q],
-                                    cv[4 * q + 1], cv[4 * q + 2], cv[4 * q + 3]);
+                panel_export_store4(ex, tstride, b, np, col, row0 + wr * 64 + tm * 32 + 8 * q + 4 * lhalf, cq[4 * q],
+                                    cq[4 * q + 1], cq[4 * q + 2], cq[4 * q + 3]);
         }
     MI32_RB_STAMP(3);
 #ifdef MI32_RB_STAMPS
@@ -277,7 +335,7 @@ __device__ __forceinline__ void rank_bw2_tile(
 #endif
 }
 
-template <int BK, int WPS, int BN = 128>
+template <int BK, int WPS, int BN = 128, bool PF = false>
 __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
     const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
@@ -288,8 +346,8 @@ __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
     if (guard != nullptr && __builtin_amdgcn_readfirstlane(guard[blockIdx.y]) == MI32_RUNTIME_ERROR) return;  // given up
     int rt, ct;
     rb_tile_of(blockIdx.x, np / 128, np / BN, rt, ct);
-    rank_bw2_tile<BK, BN>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
-                          copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
+    rank_bw2_tile<BK, BN, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
+                              copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
 }
 
 // Persistent, residency-limited flavour for the look-ahead half (see blocked_invert): gridDim.x workgroups
@@ -297,7 +355,7 @@ __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
 // fewer workgroups than CUs, so a known number of CUs stays entirely free for the critical-path kernels
 // of the main stream (the panel kernel needs a whole CU); stream priorities cannot give that guarantee
 // and a CU mask serialises the queues.
-template <int BK>
+template <int BK, bool PF = false>
 __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
     const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
@@ -310,8 +368,8 @@ __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
     for (int id = blockIdx.x; id < T * T; id += gridDim.x) {
         int rt, ct;
         rb_tile_of(id, T, T, rt, ct);
-        rank_bw2_tile<BK>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
-                          copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
+        rank_bw2_tile<BK, 128, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
+                                   copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
         __syncthreads();  // the next tile re-uses the LDS buffers and maps
     }
 }
