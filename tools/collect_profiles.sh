@@ -44,4 +44,5 @@ python3 bench.py --n 2048 --batch 64 --steps 5 --warmup 2 > "$OUT/bench_c2.json"
 python3 bench.py --n 16384 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.log"; echo "bench c4 done"
 python3 bench.py --algo sweep --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c1_sweep.json" 2> "$OUT/bench_c1_sweep.log"; echo "bench sweep done"
 python3 tools/pmc_traffic.py "$OUT" "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.log" 2>&1
+python3 tools/pmc_sq_summary.py "$OUT" "$OUT/pmc_sq_summary.json" > "$OUT/pmc_sq_summary.log" 2>&1
 ls "$OUT" | head -80
