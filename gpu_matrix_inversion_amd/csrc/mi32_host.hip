@@ -748,9 +748,33 @@ static void fill_times10(double *times10, const double *ms, std::chrono::steady_
 // res_struct.h:4-6 -- [0] queue/context, [1] buffers (+ the H2D copy the reference's CL_MEM_COPY_HOST_PTR does),
 // [2] program build, [3] makeAugmented, [4] pivot, [5] row, [6] column, [7] compute, [8] getInverted (+ D2H),
 // [9] total; seconds.  The per-phase slots come from HIP events on the launch stream (mi32_set_profiling).
-static int host_invert_32(const float *a, int n, int batch, float *inv, int *status, double *times10)
+// First touch of a large, freshly allocated result buffer on several threads: the kernel hands out zeroed pages one fault
+// at a time (64 MiB: ~12 ms on one thread of the MI355X host, ~2 ms on eight).
+static void parallel_first_touch(void *p, size_t bytes)
 {
-    if (!a || !inv || n <= 0 || batch <= 0) return MI32_BAD_SHAPE;
+    const size_t kMin = (size_t)8 << 20;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
+    if (bytes < 2 * kMin || nt == 1) { std::memset(p, 0, bytes); return; }
+    const size_t chunk = ((bytes / nt) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nt; ++i) {
+        const size_t lo = (size_t)i * chunk;
+        if (lo >= bytes) break;
+        const size_t len = (lo + chunk <= bytes) ? chunk : bytes - lo;
+        try { th.emplace_back([=] { std::memset((char *)p + lo, 0, len); }); } catch (...) { std::memset((char *)p + lo, 0, len); }
+    }
+    std::memset(p, 0, chunk < bytes ? chunk : bytes);
+    for (auto &t : th) t.join();
+}
+
+// `late_out`: where the result goes is only asked for once the kernels are queued -- the std::vector entry points
+// allocate and first-touch their 4 N^2 result bytes (64 MiB of page faults at N = 4096, ~8 ms) while the device works
+typedef void *(*LateOut)(void *ctx);
+static int host_invert_32(const float *a, int n, int batch, float *inv, int *status, double *times10,
+                          LateOut late_out = nullptr, void *late_ctx = nullptr)
+{
+    if (!a || (!inv && !late_out) || n <= 0 || batch <= 0) return MI32_BAD_SHAPE;
     const auto tq0 = std::chrono::steady_clock::now();
     mi32_context *h = nullptr;
     int rc = default_context(&h);  // the reference's platform / device / context / queue bring-up (cached here)
@@ -774,6 +798,10 @@ static int host_invert_32(const float *a, int n, int batch, float *inv, int *sta
     const auto t1 = std::chrono::steady_clock::now();
     rc = mi32_inv_device(h, h->d_in, n, batch, h->d_out, h->d_status);
     if (rc != MI32_OK) return rc;
+    if (late_out) {
+        inv = static_cast<float *>(late_out(late_ctx));
+        if (!inv) { (void)hipStreamSynchronize(h->stream); return MI32_RUNTIME_ERROR; }
+    }
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t2 = std::chrono::steady_clock::now();
     std::vector<int> st((size_t)batch);
@@ -829,7 +857,7 @@ int mi32_matrix_inv_32(const float *a_rowmajor, size_t a_len, int n, float *inv_
 }
 
 static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor, bool pivoting,
-                          double *times10);
+                          double *times10, LateOut late_out = nullptr, void *late_ctx = nullptr);
 
 int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor)
 {
@@ -848,12 +876,12 @@ int mi32_bench_64(const double *a_rowmajor, size_t a_len, int n, double *inv_row
 }
 
 static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor, bool pivoting,
-                          double *times10)
+                          double *times10, LateOut late_out, void *late_ctx)
 {
     // the guards of the fp32 library (mat_inv_32.cpp:206-215); matrix_inversion_FP64.cpp has the same two
     if (n <= 0) return MI32_BAD_SHAPE;
     if ((int)(a_len / (size_t)n) != n) return MI32_BAD_SHAPE;
-    if (!a_rowmajor || !inv_rowmajor) return MI32_BAD_SHAPE;
+    if (!a_rowmajor || (!inv_rowmajor && !late_out)) return MI32_BAD_SHAPE;
     const auto tq0 = std::chrono::steady_clock::now();
     mi32_context *h = nullptr;
     int rc = default_context(&h);
@@ -881,6 +909,10 @@ static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double 
         h->pivoting = saved;
     }
     if (rc != MI32_OK) return rc;
+    if (late_out) {
+        inv_rowmajor = static_cast<double *>(late_out(late_ctx));
+        if (!inv_rowmajor) { (void)hipStreamSynchronize(h->stream); return MI32_RUNTIME_ERROR; }
+    }
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t2 = std::chrono::steady_clock::now();
     int st = MI32_OK;
@@ -948,8 +980,19 @@ std::vector<float> matrix_inv_32(std::vector<float> matrix_vector, int matrix_or
 {
     if (matrix_order <= 0) return {};                                        // mat_inv_32.cpp:206-208
     if ((int)(matrix_vector.size() / (size_t)matrix_order) != matrix_order) return {};  // :211-214
-    std::vector<float> result((size_t)matrix_order * matrix_order, 0.0f);
-    const int rc = mi32_matrix_inv_32(matrix_vector.data(), matrix_vector.size(), matrix_order, result.data());
+    // the result vector comes into being (value-initialised, every page touched) while the device works
+    std::vector<float> result;
+    struct Ctx { std::vector<float> *v; size_t n; } ctx = {&result, (size_t)matrix_order * matrix_order};
+    const int rc = host_invert_32(matrix_vector.data(), matrix_order, 1, nullptr, nullptr, nullptr,
+                                  [](void *c) -> void * {
+                                      Ctx *x = static_cast<Ctx *>(c);
+                                      try {
+                                          x->v->reserve(x->n);  // pages first (several threads), then the value-initialisation
+                                          parallel_first_touch(x->v->data(), x->n * sizeof(float));
+                                          x->v->assign(x->n, 0.0f);
+                                      } catch (...) { return nullptr; }
+                                      return x->v->data();
+                                  }, &ctx);
     if (rc == MI32_OK) return result;
     // README.md:54 "In case of invalid matrix an empty vector is returned"; the experiment twin
     // does so for a singular input (matrix_inversion_FP32.cpp:814-835).  MI32_SINGULAR_KEEP=1
@@ -1034,8 +1077,18 @@ std::vector<double> matrix_inversion_FP64(std::vector<double> matrix_vector, int
 {
     if (matrix_order <= 0) return {};
     if ((int)(matrix_vector.size() / (size_t)matrix_order) != matrix_order) return {};
-    std::vector<double> result((size_t)matrix_order * matrix_order, 0.0);
-    const int rc = mi32_matrix_inv_64(matrix_vector.data(), matrix_vector.size(), matrix_order, result.data());
+    std::vector<double> result;  // allocated and first touched while the device works (see matrix_inv_32)
+    struct Ctx { std::vector<double> *v; size_t n; } ctx = {&result, (size_t)matrix_order * matrix_order};
+    const int rc = host_invert_64(matrix_vector.data(), matrix_vector.size(), matrix_order, nullptr, true, nullptr,
+                                  [](void *c) -> void * {
+                                      Ctx *x = static_cast<Ctx *>(c);
+                                      try {
+                                          x->v->reserve(x->n);
+                                          parallel_first_touch(x->v->data(), x->n * sizeof(double));
+                                          x->v->assign(x->n, 0.0);
+                                      } catch (...) { return nullptr; }
+                                      return x->v->data();
+                                  }, &ctx);
     if (rc == MI32_OK) return result;
     // a singular input: {} like the reference (its exact-identity check, matrix_inversion_FP64.cpp:846-867)
     if (rc == MI32_SINGULAR && env_int("MI32_SINGULAR_KEEP", 0)) return result;
