@@ -1290,7 +1290,12 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     }
     // dynamic LDS of the rank-bw kernels: operand stages + maps; the persistent flavour asks for more than half
     // a CU's LDS so that at most one of its workgroups is resident per CU
-    const size_t lds_persistent = 84 * 1024;
+    // "exclusive": nearly all of a CU's LDS, so that no workgroup of the main stream fits beside a look-ahead workgroup.
+    // The dispatcher deals a grid's workgroups to the XCDs and shader engines in turn and puts each on the FIRST CU of
+    // its engine that has room -- with 84 KB the in-block update tiles and the small panels land on the CUs the
+    // look-ahead half keeps busy although whole CUs are idle (in-block update 12.2 instead of 6.4 us while the half
+    // runs).  Where the half is short against the panel phase (up to ~8192 rows) it gets fewer CUs, all to itself.
+    const size_t lds_persistent = (ex.aux_exclusive ? 156 : 84) * 1024;
     {
         static bool attr_set_dev[64] = {};  // function attributes are per device
         int dev = 0;
@@ -1301,7 +1306,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)rank_bw2_lds_bytes<MI32_BW_BK>(kMaxBW));
             (void)hipFuncSetAttribute((const void *)gj_rank_bw2_persistent_kernel<MI32_BW_BK>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_persistent);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
             attr_set = true;
         }
     }

@@ -222,8 +222,7 @@ struct mi32_context {
     hipStream_t aux_stream = nullptr;   // look-ahead half of the rank-bw updates (lowest priority)
     hipStream_t split_stream = nullptr; // second half of a split batch (same priority as the main stream)
     hipEvent_t la_events[8] = {};
-    int aux_workgroups = 0;
-    int aux_workgroups_large = 0;  // ... for matrices of 8192 rows and more
+    int cu_count = 0;
     bool lookahead = true;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -265,6 +264,35 @@ static int env_int(const char *name, int dflt)
 {
     const char *s = std::getenv(name);
     return (s && *s) ? std::atoi(s) : dflt;
+}
+
+// The look-ahead half of a single large matrix (blocked_invert): how many CUs it runs on and whether it shares them.
+// Measured on MI355X (256 CUs), ms per inversion, "free CUs / LDS KB per look-ahead workgroup":
+//   N  4096:  32/84 8.81   32/156 8.66   64/156 8.53   96/156 8.51   128/156 8.49
+//   N  6144:  16/84 18.96  32/84 17.88   32/156 17.78  64/156 17.01  128/156 17.33
+//   N  8192:  16/84 30.6   32/156 30.3   64/156 29.5
+//   N 10240:  16/84 41.7   32/84 40.6    32/156 42.1   64/156 40.9   128/156 50.2
+//   N 12288:  16/84 58.5   32/84 57.9    32/156 59.0   64/156 60.8   128/156 84.7
+//   N 16384:  16/84 107.5  32/84 111.4   32/156 125.4  64/156 124.3  (8/84 107.0, 5/84 137.7: the shared panels starve)
+// Up to ~8192 rows the half is short against the panel phase: it gets few CUs, all to itself, and the panel chain
+// keeps the rest undisturbed; above, every block waits for the half: it gets all but 32 / 16 CUs and shares them.
+// MI32_RESERVED_CUS / MI32_LA_EXCLUSIVE override.
+static void lookahead_geometry(int cus, int n, int *workgroups, bool *exclusive)
+{
+    int reserve;
+    bool excl;
+    if (n < 5120) { reserve = cus / 2; excl = true; }
+    else if (n <= 9216) { reserve = cus / 4; excl = true; }
+    else if (n <= 14336) { reserve = cus / 8; excl = false; }
+    else { reserve = cus / 16; excl = false; }
+    const int r_env = env_int("MI32_RESERVED_CUS", 0);
+    if (r_env > 0) reserve = r_env;
+    if (reserve < 1) reserve = 1;
+    if (reserve > cus - 1) reserve = cus - 1;
+    const int x_env = env_int("MI32_LA_EXCLUSIVE", -1);
+    if (x_env >= 0) excl = x_env != 0;
+    *workgroups = cus - reserve;
+    *exclusive = excl;
 }
 
 static int resolve_algo(const mi32_context *h, int n)
@@ -386,17 +414,7 @@ int mi32_create(mi32_handle_t *out, int device)
         // serialises the two queues, 17 ms instead of 11.5.)
         hipDeviceProp_t prop;
         MI32_HIP(hipGetDeviceProperties(&prop, device));
-        int reserve = env_int("MI32_RESERVED_CUS", 32);
-        if (reserve < 1) reserve = 1;
-        if (reserve > prop.multiProcessorCount / 2) reserve = prop.multiProcessorCount / 2;
-        h->aux_workgroups = prop.multiProcessorCount - reserve;
-        // From 8192 rows on every block waits for its look-ahead half, not for the panels: 16 free CUs are enough for
-        // the (up to 4) panel workgroups, and the half gets the other 16 (measured 16384^2: 111.4 -> 107.6 ms,
-        // 8192^2: 30.0 -> 29.7 ms; at 4096^2 the in-block updates want the free CUs: 8.82 -> 9.11 ms; 5 free CUs
-        // starve the shared panels: 137.7 ms).
-        h->aux_workgroups_large = env_int("MI32_RESERVED_CUS", 0) > 0 ? h->aux_workgroups
-                                                                    : prop.multiProcessorCount - 16;
-        if (h->aux_workgroups_large < h->aux_workgroups) h->aux_workgroups_large = h->aux_workgroups;
+        h->cu_count = prop.multiProcessorCount;
         int prio_low = 0, prio_high = 0;
         MI32_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         MI32_HIP(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_low));
@@ -555,7 +573,7 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
         ex.aux = h->lookahead ? h->aux_stream : nullptr;
         ex.events = h->la_events;
         ex.n_events = h->aux_stream ? 8 : 0;
-        ex.aux_workgroups = (n >= 8192) ? h->aux_workgroups_large : h->aux_workgroups;
+        lookahead_geometry(h->cu_count, n, &ex.aux_workgroups, &ex.aux_exclusive);
         ex.prof = h->prof;
         const BlockedPlan p = plan_blocked(h, n, batch);
         if (!split_batch(h, algo, n, batch)) {

@@ -122,6 +122,7 @@ struct BlockedExec {
     hipEvent_t *events = nullptr;
     int n_events = 0;
     int aux_workgroups = 0;  // grid of the persistent look-ahead kernel: CUs minus the ones kept free
+    bool aux_exclusive = false;  // its workgroups take a whole CU's LDS: nothing of the main stream shares their CUs
     Profiler *prof = nullptr;
 };
 hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *ws,
