@@ -1267,8 +1267,9 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     hipStream_t stream = ex.stream;
     Profiler *prof = ex.prof;
     // look-ahead pays when the GPU is otherwise idle during the panel phase: a single large matrix
-    // (measured: 8192^2 51 -> 45 ms, 16384^2 399 -> 330 ms, 4096^2 11.2 -> 11.0 ms, 2048^2 4.2 -> 4.4 ms)
-    const bool lookahead = ex.aux != nullptr && ex.n_events >= 4 && ex.aux_workgroups > 0 && batch == 1 && np >= 4096;
+    // (measured in round 1: 8192^2 51 -> 45 ms, 16384^2 399 -> 330 ms, 4096^2 11.2 -> 11.0 ms, 2048^2 4.2 -> 4.4 ms; with
+    // the half on CUs of its own, round 2: 3584^2 7.39 -> 7.00 ms, 3072^2 5.79 -> 5.63, 2560^2 4.32 -> 4.34, 2048^2 3.01 -> 3.14)
+    const bool lookahead = ex.aux != nullptr && ex.n_events >= 4 && ex.aux_workgroups > 0 && batch == 1 && np >= 3072;
     hipError_t e;
     int fused_rows = 2048;  // see "Fused mode" below; fused instances exist for at most 2048 rows
     if (const char *ev = std::getenv("MI32_FUSED_ROWS")) fused_rows = std::atoi(ev) < 2048 ? std::atoi(ev) : 2048;

@@ -483,6 +483,27 @@ def test_c1_4096_default_plan_bit_identical_to_mirror(oracle):
     check_against_mirror_digest(got, dig)
 
 
+@pytest.mark.parametrize("n", [3072, 3500, 6100])
+def test_lookahead_sizes_bit_identical_to_mirror(oracle, n):
+    """The look-ahead schedule outside 4096: its lower end (3072 padded rows on; the half runs on half of the CUs,
+    with a whole CU's LDS per workgroup), a ragged size in between, and 6100 (6144 padded rows: the first panels are
+    shared by two workgroups, the half runs on three quarters of the CUs) -- with the second stream and without it,
+    bit for bit the oracle's blocked mirror."""
+    a = gate_matrix(n, 7000 + n)
+    inv = _default_inverter()
+    try:
+        widths, bw = inv.resolved_panel_widths(n, 1), inv.resolved_blocking(n, 1)[1]
+        got, st = run(inv, a)
+        inv.set_lookahead(False)
+        got1, st1 = run(inv, a)
+    finally:
+        inv.close()
+    want, info = oracle.matrix_inv_32_blocked2(a, n, widths, bw, return_info=True)
+    assert st[0] == st1[0] == info["status"] == 0
+    assert np.array_equal(got.reshape(-1), want)
+    assert np.array_equal(got1.reshape(-1), want)
+
+
 @pytest.mark.parametrize("kind", ["ref100", "rand", "hollow"])
 def test_c1_4096_reference_distributions_bit_identical_to_mirror(oracle, kind):
     """N = 4096 on the reference's own input distributions (U(0,100) of matrix_inv_pyopencl.py:17 / matrix_inv_numpy.py:40,
