@@ -23,6 +23,7 @@ from .oracle import (  # noqa: F401
     matrix_inv_32,
     matrix_inv_32_blocked,
     matrix_inv_32_blocked2,
+    matrix_inv_32_blocked_exact,
     matrix_inv_32_inplace,
     matrix_inv_64,
     matrix_inv_64_blocked,

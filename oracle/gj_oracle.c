@@ -710,6 +710,146 @@ int gjo_matrix_inv_32_blocked2(const float *in, size_t in_len, int n, float *out
     return gjo_matrix_inv_32_blocked2w(in, in_len, n, out, &w, 1, bw, pivots);
 }
 
+/* ---- blocked restatement with the SEQUENTIAL arithmetic (round 3) --------------------------------------------
+ * The same elimination as inv32_inplace_impl -- one fmaf per element and pivot step (R:28-38), one IEEE division
+ * per element of a pivot row (R:149), exact-zero multipliers skipped (R:28) -- evaluated block by block:
+ *   panel   : the bw pivot steps on the block's own columns, all rows; every step's MULTIPLIER column
+ *             f[i] = m[i][r] (R:30, the value fixColumn reads before it overwrites the column) is kept, and the
+ *             pivot itself in the pivot row's slot: mult[i][s].  Row swaps move a row's multiplier history with it.
+ *   strip   : for every other column j, the bw pivot rows alone run the bw steps in order: row s is divided by its
+ *             pivot (-> u[s][j], the pivot row as fixColumn sees it at step s), every other pivot row takes
+ *             fmaf(-mult[k][s], u[s][j], x[k]).
+ *   update  : every other row i: x = fmaf(-mult[i][s], u[s][j], x) for s ascending.
+ * Every element goes through exactly the operations the step-by-step loop applies to it, in the same order, so the
+ * result is BIT-IDENTICAL to gjo_matrix_inv_32_inplace for every block width (tests/test_oracle.py) -- this is the
+ * operation order of the HIP blocked path from round 3 on, and a cache-friendly way of computing the reference-order
+ * result at the BASELINE sizes in seconds. */
+int gjo_matrix_inv_32_blocked_exact(const float *in, size_t in_len, int n, float *out, int bw, int *pivots)
+{
+    if (!shape_ok(in_len, n)) return GJO_BAD_SHAPE;
+    if (bw <= 0) bw = 64;
+    if (bw > n) bw = n;
+    const size_t ld = (size_t)n;
+    float *m = (float *)malloc(sizeof(float) * ld * n);
+    int *orig = (int *)malloc(sizeof(int) * n);
+    float *mult = (float *)malloc(sizeof(float) * (size_t)n * bw);
+    float *us = (float *)malloc(sizeof(float) * (size_t)bw * n);
+    float *prn = (float *)malloc(sizeof(float) * bw);
+    if (!m || !orig || !mult || !us || !prn) {
+        free(m); free(orig); free(mult); free(us); free(prn);
+        return GJO_BAD_SHAPE;
+    }
+    memcpy(m, in, sizeof(float) * ld * n);
+    for (int i = 0; i < n; ++i) orig[i] = i;
+    int status = input_status_f32(in, n);
+
+    for (int c0 = 0; c0 < n; c0 += bw) {
+        const int kw = (c0 + bw <= n) ? bw : n - c0;
+        /* panel: the unblocked steps on the columns [c0, c0 + kw), multipliers kept */
+        for (int s = 0; s < kw; ++s) {
+            const int r = c0 + s;
+            const int p = max_pivot_true(m, ld, n, r);
+            const float piv = m[(size_t)p * ld + r];
+            if (pivots) pivots[r] = p;
+            if (bad_pivot((double)piv)) status = GJO_SINGULAR;
+            if (p != r) { /* pivotElements, R:154-173: all columns, and the rows' multiplier histories */
+                for (int j = 0; j < n; ++j) {
+                    float t = m[(size_t)r * ld + j];
+                    m[(size_t)r * ld + j] = m[(size_t)p * ld + j];
+                    m[(size_t)p * ld + j] = t;
+                }
+                for (int k = 0; k < s; ++k) {
+                    float t = mult[(size_t)r * bw + k];
+                    mult[(size_t)r * bw + k] = mult[(size_t)p * bw + k];
+                    mult[(size_t)p * bw + k] = t;
+                }
+                int t = orig[r]; orig[r] = orig[p]; orig[p] = t;
+            }
+            float *mr = m + (size_t)r * ld + c0;
+            for (int c = 0; c < kw; ++c) prn[c] = mr[c] / piv;
+            prn[s] = 1.0f / piv;
+            for (int c = 0; c < kw; ++c) mr[c] = prn[c];
+            mult[(size_t)r * bw + s] = piv;
+            for (int i = 0; i < n; ++i) {
+                if (i == r) continue;
+                float *mi = m + (size_t)i * ld + c0;
+                const float f = mi[s];
+                mult[(size_t)i * bw + s] = f;
+                mi[s] = 0.0f;
+                if (f != 0.0f)
+                    for (int c = 0; c < kw; ++c) mi[c] = fmaf(-f, prn[c], mi[c]);
+            }
+        }
+        if (kw == n) break;
+        /* strip: the kw pivot rows (positions c0 .. c0+kw-1) over every other column, 64 columns at a time */
+#ifdef _OPENMP
+        const int nthreads = ((double)n * kw * n > 4e7) ? oracle_threads() : 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int jn = (j0 + 64 <= n) ? 64 : n - j0;
+            for (int s = 0; s < kw; ++s) {
+                float *xs = m + (size_t)(c0 + s) * ld + j0;
+                float *u = us + (size_t)s * n + j0;
+                const float piv = mult[(size_t)(c0 + s) * bw + s];
+                for (int j = 0; j < jn; ++j) {
+                    const int jj = j0 + j;
+                    if (jj >= c0 && jj < c0 + kw) continue;
+                    xs[j] = xs[j] / piv;
+                    u[j] = xs[j];
+                }
+                for (int k = 0; k < kw; ++k) {
+                    if (k == s) continue;
+                    const float f = mult[(size_t)(c0 + k) * bw + s];
+                    if (f == 0.0f) continue;
+                    float *xk = m + (size_t)(c0 + k) * ld + j0;
+                    for (int j = 0; j < jn; ++j) {
+                        const int jj = j0 + j;
+                        if (jj >= c0 && jj < c0 + kw) continue;
+                        xk[j] = fmaf(-f, u[j], xk[j]);
+                    }
+                }
+            }
+        }
+        /* update: every row outside the block's pivot rows */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+        for (int i = 0; i < n; ++i) {
+            if (i >= c0 && i < c0 + kw) continue;
+            float *mi = m + (size_t)i * ld;
+            const float *f = mult + (size_t)i * bw;
+            for (int part = 0; part < 2; ++part) {
+                const int ja = part ? c0 + kw : 0, jb = part ? n : c0;
+                int j = ja;
+#if defined(__AVX2__) && defined(__FMA__)
+                for (; j + 32 <= jb; j += 32) {
+                    __m256 acc[4];
+                    for (int v = 0; v < 4; ++v) acc[v] = _mm256_loadu_ps(mi + j + 8 * v);
+                    for (int k = 0; k < kw; ++k) {
+                        if (f[k] == 0.0f) continue;
+                        const __m256 fb = _mm256_set1_ps(f[k]);
+                        const float *r = us + (size_t)k * n + j;
+                        for (int v = 0; v < 4; ++v) acc[v] = _mm256_fnmadd_ps(fb, _mm256_loadu_ps(r + 8 * v), acc[v]);
+                    }
+                    for (int v = 0; v < 4; ++v) _mm256_storeu_ps(mi + j + 8 * v, acc[v]);
+                }
+#endif
+                for (; j < jb; ++j) {
+                    float acc = mi[j];
+                    for (int k = 0; k < kw; ++k)
+                        if (f[k] != 0.0f) acc = fmaf(-f[k], us[(size_t)k * n + j], acc);
+                    mi[j] = acc;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < n; ++c) out[(size_t)i * n + orig[c]] = m[(size_t)i * ld + c];
+    free(m); free(orig); free(mult); free(us); free(prn);
+    return status;
+}
+
 /* ---- metrics ----------------------------------------------------------- */
 static double residual_generic(const float *l, const float *r, int n)
 {

@@ -99,6 +99,11 @@ int gjo_matrix_inv_32_blocked2(const float *in, size_t in_len, int n, float *out
 int gjo_matrix_inv_32_blocked2w(const float *in, size_t in_len, int n, float *out, const int *w_of_block,
                                 int nblocks, int bw, int *pivots);
 
+/* Blocked evaluation of the SEQUENTIAL arithmetic (multipliers kept, pivot-row strip, fmaf chains from the old
+ * value): bit-identical to gjo_matrix_inv_32_inplace (GJO_ARITH_FMA) for every block width bw; the operation order
+ * of the HIP blocked path from round 3 on. */
+int gjo_matrix_inv_32_blocked_exact(const float *in, size_t in_len, int n, float *out, int bw, int *pivots);
+
 /* ||A*X - I||_inf (max abs row sum), product accumulated in double. */
 double gjo_residual_inf(const float *a, const float *x, int n);
 /* ||X*A - I||_inf: the side the reference's Python scripts check (PY:341). */

@@ -79,6 +79,8 @@ def _load():
     lib.gjo_matrix_inv_64_nopivot.argtypes = [dp, ctypes.c_size_t, ctypes.c_int, dp]
     lib.gjo_matrix_inv_32_nopivot.restype = ctypes.c_int
     lib.gjo_matrix_inv_32_nopivot.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ctypes.c_int]
+    lib.gjo_matrix_inv_32_blocked_exact.restype = ctypes.c_int
+    lib.gjo_matrix_inv_32_blocked_exact.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ctypes.c_int, ip]
     lib.gjo_matrix_inv_32_blocked2w.restype = ctypes.c_int
     lib.gjo_matrix_inv_32_blocked2w.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ip, ctypes.c_int, ctypes.c_int, ip]
     for nm in ("gjo_residual_inf", "gjo_residual_inf_left", "gjo_frobenius_metric"):
@@ -229,6 +231,25 @@ def matrix_inv_32_blocked2(vec, n: int, w=16, bw: int = 256, return_info: bool =
     else:
         st = lib.gjo_matrix_inv_32_blocked2(_fp(v), v.size, n, _fp(out), int(w), int(bw),
                                             piv.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if return_info:
+        return out, {"status": st, "pivots": piv}
+    return out
+
+
+def matrix_inv_32_blocked_exact(vec, n: int, bw: int = 64, return_info: bool = False):
+    """The SEQUENTIAL arithmetic (one fmaf per element and step, IEEE division of the pivot rows) evaluated block
+    by block: bit-identical to ``matrix_inv_32_inplace`` for every ``bw`` -- the HIP blocked path's operation order
+    from round 3 on, and the fast way to the reference-order result at the BASELINE sizes (N = 4096 in ~2 s)."""
+    lib = _load()
+    v = _f32(vec)
+    n = int(n)
+    if n <= 0 or int(v.size // n) != n:
+        empty = np.empty(0, dtype=np.float32)
+        return (empty, {"status": STATUS_BAD_SHAPE}) if return_info else empty
+    out = np.empty(n * n, dtype=np.float32)
+    piv = np.empty(n, dtype=np.int32)
+    st = lib.gjo_matrix_inv_32_blocked_exact(_fp(v), v.size, n, _fp(out), int(bw),
+                                             piv.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
     if return_info:
         return out, {"status": st, "pivots": piv}
     return out

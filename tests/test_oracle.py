@@ -144,6 +144,40 @@ def test_blocked_restatement_within_tolerance(oracle, n, w):
     assert oracle.residual_inf(a, y, n) < 1e-4
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 16, 33, 64, 100, 130, 257, 700])
+def test_blocked_exact_is_bit_identical_to_the_step_by_step_restatement(oracle, n):
+    """The blocked evaluation the HIP blocked path follows from round 3 on (multipliers kept, pivot-row strip, one
+    fmaf chain per element from the old value) is the reference-order elimination bit for bit -- for every block
+    width, on the well-conditioned gate matrices and on the reference's own ill-conditioned U(0,100) / rand inputs
+    (matrix_inv_pyopencl.py:17, test_inversa_mat.mlx), sign of zeros included."""
+    mats = [gate_matrix(n, 7000 + n),
+            np.random.default_rng(7100 + n).uniform(0, 100, (n, n)).astype(np.float32),
+            np.random.default_rng(7200 + n).uniform(0, 1, (n, n)).astype(np.float32)]
+    if n >= 7:
+        h = mats[1].copy()
+        np.fill_diagonal(h, 0.0)  # hollow (matrix_inv_numpy.py:13-14): pivoting from step 0, exact-zero multipliers
+        h[n // 2, : n // 3] = 0.0
+        mats.append(h)
+    for a in mats:
+        x, i1 = oracle.matrix_inv_32_inplace(a, n, return_info=True)
+        for bw in (1, 5, 16, 64, 256):
+            y, i2 = oracle.matrix_inv_32_blocked_exact(a, n, bw, return_info=True)
+            assert i1["status"] == i2["status"]
+            assert np.array_equal(i1["pivots"], i2["pivots"])
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (n, bw)
+
+
+def test_blocked_exact_singular_inputs_agree_with_the_step_by_step_restatement(oracle):
+    n = 40
+    a = np.random.default_rng(3).uniform(-1, 1, (n, n)).astype(np.float32)
+    a[:, 11] = 0.0  # a zero pivot in step 11: inf / NaN from there on
+    x, i1 = oracle.matrix_inv_32_inplace(a, n, return_info=True)
+    y, i2 = oracle.matrix_inv_32_blocked_exact(a, n, 16, return_info=True)
+    assert i1["status"] == i2["status"] == oracle.STATUS_SINGULAR
+    assert np.array_equal(i1["pivots"], i2["pivots"])
+    assert np.array_equal(x, y, equal_nan=True)  # the same inf / NaN pattern (the sign bit of a NaN is not specified)
+
+
 def test_shape_guards_return_empty(oracle):
     """mat_inv_32.cpp:206-215: N <= 0 -> {}, int(size/N) != N -> {} (integer division, so a tail
     of fewer than N extra floats is accepted and ignored)."""
