@@ -65,9 +65,8 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 #define MI32_BW_BK 16
 #endif
 #ifndef MI32_BW_PF
-#define MI32_BW_PF 1   // the old values of a tile are fetched under the last k-tiles (mi32_rank_bw.h); the full-chip
-                       // kernel only: 4096^2 88.9 -> 86.6 us per launch, 64 x 2048^2 740 -> 704 us; the one-per-CU
-                       // look-ahead flavour loses with it (16384^2 110.9 -> 115.4 ms)
+#define MI32_BW_PF 0   // (round 2 fetched the old values of a tile under its last k-tiles; the accumulation from the old
+                       // value, round 3, needs them in front of the k-loop)
 #endif
 #ifndef MI32_BW_WPS
 #define MI32_BW_WPS (MI32_BW_PF ? 2 : 3)   // the prefetch keeps 64 more registers live: two workgroups per CU
@@ -155,24 +154,37 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct BlockedWs {
     float *m0, *m1;     // the two working copies, np x ld each
     float *pt[3];       // compact transposed panel inputs, kMaxW x np each: sub-panel s of a block uses pt[s % 3]
-    float *gt[2];       // compact transposed panel outputs G_s: gt[s & 1]
-    float *aux[2];      // per sub-panel: the W normalised pivot rows, and the previous sub-panel's pivot rows
-                        // restricted to this sub-panel's columns (2 x kMaxW x kMaxW floats per matrix)
+    float *gt[2];       // compact transposed panel outputs G_s (the new values of the sub-panel's own columns): gt[s & 1]
+    float *mt[2];       // compact transposed MULTIPLIERS of sub-panel s, kMaxW x mtld each: mt[s & 1]
+    float *aux[2];      // per sub-panel, kAuxFloats per matrix: the W normalised pivot rows; the previous sub-panel's
+                        // pivot rows as its steps saw them (U_{s-1}) restricted to this sub-panel's columns; the W x W
+                        // multipliers of the sub-panel's own pivot rows
     unsigned long long *xch;  // exchange granules of the multi-workgroup panels, kXchGranules per matrix
-    float *gk;          // the block's panel G transposed, bw x np: A operand of the rank-bw update
-    size_t gkstride;    // floats per matrix in gk
+    float *mf[2];       // the block's NEGATED multipliers, np x bw row-major BY BLOCK-START ROW INDEX (never permuted);
+                        // double-buffered across blocks (the look-ahead half reads block b's while block b+1 runs)
+    float *ub[2];       // the block's pivot rows as their own steps saw them (U), bw x np: B operand of the rank-bw update
+    float *gk;          // the block's multipliers transposed and in final row order, bw x np: its A operand
+    size_t gkstride;    // floats per matrix in gk / ub
+    size_t mfstride;    // floats per matrix in mf
     int *submap[2], *invsub[2];  // per sub-panel: position after s -> index in order after s-1, and its inverse
-    int *rowsrc[2], *orig, *invp;  // rowsrc is double-buffered across blocks (look-ahead)
+    int *rowsrc[4], *orig, *invp;  // rowsrc[2 * (blk & 1) + (fused ? s & 1 : 0)]: double-buffered across blocks
+                                   // (look-ahead) and, in fused blocks, across sub-panels (update(s-1) reads the map
+                                   // panel(s) rewrites in the same launch)
     size_t mstride;     // floats per matrix in m0/m1
     size_t tstride;     // floats per matrix in pt/gt
+    size_t mtstride;    // floats per matrix in mt
+    int mtld;           // row stride of mt: every register row of a panel workgroup has a slot (rows >= np too)
     size_t pt_bstride;  // floats between pt[i] and pt[i + 1]
 };
+static constexpr int kAuxFloats = 2 * kMaxW * kMaxW;
 static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, BlockedWs *o)
 {
     const size_t mbytes = align256((size_t)p.np * p.ld * sizeof(float));
     const size_t tbytes = align256((size_t)kMaxW * p.np * sizeof(float));
     const size_t ibytes = align256((size_t)p.np * sizeof(int) * batch);
-    const size_t abytes = align256((size_t)2 * kMaxW * kMaxW * sizeof(float) * batch);
+    const size_t abytes = align256((size_t)kAuxFloats * sizeof(float) * batch);
+    const int mtld = 2 * p.np + 256;  // row_lo + NT * RPT <= 2 np + 256 for every panel geometry
+    const size_t mtbytes = align256((size_t)kMaxW * mtld * sizeof(float));
     char *c = (char *)base;
     size_t off = 0;
     if (o) {
@@ -180,6 +192,8 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
         o->mstride = mbytes / sizeof(float);
         o->tstride = tbytes / sizeof(float);
         o->pt_bstride = tbytes * batch / sizeof(float);
+        o->mtstride = mtbytes / sizeof(float);
+        o->mtld = mtld;
     }
     off += mbytes * batch;
     if (o) o->m1 = (float *)(c + off);
@@ -193,6 +207,10 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
         off += tbytes * batch;
     }
     for (int i = 0; i < 2; ++i) {
+        if (o) o->mt[i] = (float *)(c + off);
+        off += mtbytes * batch;
+    }
+    for (int i = 0; i < 2; ++i) {
         if (o) o->aux[i] = (float *)(c + off);
         off += abytes;
     }
@@ -201,10 +219,21 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
     const size_t gkbytes = align256((size_t)(p.bw < kMaxBW ? p.bw : kMaxBW) * p.np * sizeof(float));
     if (o) { o->gk = (float *)(c + off); o->gkstride = gkbytes / sizeof(float); }
     off += gkbytes * batch;
-    int **maps[8] = {o ? &o->submap[0] : nullptr, o ? &o->submap[1] : nullptr, o ? &o->invsub[0] : nullptr,
-                     o ? &o->invsub[1] : nullptr, o ? &o->rowsrc[0] : nullptr, o ? &o->rowsrc[1] : nullptr,
-                     o ? &o->orig : nullptr,      o ? &o->invp : nullptr};
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 2; ++i) {
+        if (o) o->ub[i] = (float *)(c + off);
+        off += gkbytes * batch;
+    }
+    const size_t mfbytes = align256((size_t)p.np * p.bw * sizeof(float));
+    if (o) o->mfstride = mfbytes / sizeof(float);
+    for (int i = 0; i < 2; ++i) {
+        if (o) o->mf[i] = (float *)(c + off);
+        off += mfbytes * batch;
+    }
+    int **maps[10] = {o ? &o->submap[0] : nullptr, o ? &o->submap[1] : nullptr, o ? &o->invsub[0] : nullptr,
+                      o ? &o->invsub[1] : nullptr, o ? &o->rowsrc[0] : nullptr, o ? &o->rowsrc[1] : nullptr,
+                      o ? &o->rowsrc[2] : nullptr, o ? &o->rowsrc[3] : nullptr,
+                      o ? &o->orig : nullptr,      o ? &o->invp : nullptr};
+    for (int i = 0; i < 10; ++i) {
         if (o) *maps[i] = (int *)(c + off);
         off += ibytes;
     }
@@ -293,6 +322,66 @@ __device__ __forceinline__ float lane_bcast(float v, int srclane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
 }
 
+// ---- the pivot-row strip: BK pivot steps on the BK pivot rows alone, one column per quad ------------
+// Every column outside a (sub-)panel sees that panel's BK pivot steps as
+//     u_m = x[row of step m] / pivot_m                       fixRow,    mat_inv_32.cpp:138-150
+//     x[i] = fmaf(-f_m[i], u_m, x[i])   for every other row  fixColumn, mat_inv_32.cpp:28-38
+// for m = 0 .. BK-1 in order, f_m[i] = the entry row i had in the pivot column when step m ran (the panel keeps
+// these multipliers).  u_m only depends on the BK pivot rows themselves: the strip runs the BK steps on them -- BK
+// dependent IEEE divisions -- and leaves u_m (what every other row multiplies with) and the pivot rows' values
+// after the last step.  The 4 lanes of a quad share one column: lane g holds the rows BK/4 * g ... of it, the row
+// of step M is broadcast with one quad_perm DPP move.  s_lt[m * LT + row] = -f_m[row] (own step: -pivot).
+// The multipliers of a step do not depend on the chain: they are read from LDS kStripAhead steps early into a
+// rotating window of registers, and scheduling barriers keep hipcc from sinking the reads back down to their uses
+// (left alone it puts two dependent LDS round trips, ~250 cycles, into each of the BK dependent steps).
+static constexpr int kStripAhead = 3;
+template <int BK, int M>
+__device__ __forceinline__ void strip_fetch(float (&nfw)[kStripAhead + 1][BK / 4], float (&pw)[kStripAhead + 1],
+                                            const float *s_lt, int LT, int g)
+{
+    constexpr int CPT = BK / 4;
+    if constexpr (M < BK) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) nfw[M % (kStripAhead + 1)][j] = s_lt[M * LT + CPT * g + j];
+        pw[M % (kStripAhead + 1)] = s_lt[M * LT + M];
+    }
+}
+template <int BK, int M>
+__device__ __forceinline__ void strip_step(float (&x)[BK / 4], float (&uu)[BK], float (&nfw)[kStripAhead + 1][BK / 4],
+                                           float (&pw)[kStripAhead + 1], const float *s_lt, int LT, int g)
+{
+    constexpr int CPT = BK / 4;
+    constexpr int kQuad = (M / CPT) * 0x55;  // quad_perm:[q,q,q,q]
+    strip_fetch<BK, M + kStripAhead>(nfw, pw, s_lt, LT, g);
+    __builtin_amdgcn_sched_barrier(0);
+    const float xm = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[M % CPT]), kQuad, 0xf, 0xf, false));
+    const float u = xm / -pw[M % (kStripAhead + 1)];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const float upd = __builtin_fmaf(nfw[M % (kStripAhead + 1)][j], u, x[j]);
+        x[j] = (j == M % CPT && g == M / CPT) ? u : upd;
+    }
+    uu[M] = u;
+    __builtin_amdgcn_sched_barrier(0);
+}
+// u_m is stored at the end, by one lane of each quad: no LDS store between the steps.
+template <int BK, int... Ms>
+__device__ __forceinline__ void strip_steps(float (&x)[BK / 4], const float *s_lt, int LT, int g, float *s_u, int LDU,
+                                            std::integer_sequence<int, Ms...>)
+{
+    float uu[BK];
+    float nfw[kStripAhead + 1][BK / 4], pw[kStripAhead + 1];
+    strip_fetch<BK, 0>(nfw, pw, s_lt, LT, g);
+    strip_fetch<BK, 1>(nfw, pw, s_lt, LT, g);
+    strip_fetch<BK, 2>(nfw, pw, s_lt, LT, g);
+    static_assert(kStripAhead == 3, "the three fetches above");
+    (strip_step<BK, Ms>(x, uu, nfw, pw, s_lt, LT, g), ...);
+    if (g == 0) {
+#pragma unroll
+        for (int m = 0; m < BK; ++m) s_u[m * LDU] = uu[m];
+    }
+}
+
 // ---- the panel: W pivot steps on a register-resident slab ----------------------
 // Each thread keeps RPT rows of the panel in registers for the whole kernel: row
 // CONTENTS never move between threads.  What a row swap changes is only an integer
@@ -309,6 +398,8 @@ struct __attribute__((aligned(16))) PanelShared {
     unsigned long long key[W];  // one cross-wave arg-max word per step, zeroed at kernel start
     float prn_all[W][W];        // the normalised pivot row of every step, exported for the rows above the block
     float bprev[W][W];          // the previous sub-panel's W pivot rows, restricted to this sub-panel's columns
+    float uprev[W][W];          // ... as that sub-panel's own steps saw them (u_m of the strip)
+    float lt[W][W + 4];         // -multipliers of those W pivot rows, [step][row]; at the end: this sub-panel's own
     unsigned gx[2][kMaxPanelGroups][W + 2];  // multi-workgroup panels: every workgroup's winner of this step
     int lost;                   // multi-workgroup panels: a partner timed out (sticky; zeroed at kernel start)
 };
@@ -354,9 +445,23 @@ struct PanelGroup {
     bool timed_out;
 };
 
-template <int NT, int RPT, int W, int R, bool MULTI>
-__device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[RPT], PanelShared<NT / 64, W> &sh,
-                                           int wave_u, int c0, bool wave_active, bool &singular, PanelGroup &pg)
+// V floats to sbase (wave-uniform) + voff bytes (per lane): global_store with a scalar base.  (Inline asm: hipcc does
+// not insert the wait state between a store of more than 8 bytes and the overwrite of its data registers here.)
+template <int V, typename T>
+__device__ __forceinline__ void mt_store(float *sbase, unsigned voff, T v)
+{
+    if constexpr (V == 1) asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase));
+    else if constexpr (V == 2) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase));
+    else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase));
+}
+
+// Every step stores its multiplier column straight away: mtp = this lane's first slot of Mt row 0 (slab order), or,
+// LBL (fused instances: the rows' labels at entry differ from their slab index), mt_base + moff[k] per row.
+template <int NT, int RPT, int W, int R, bool MULTI, bool LBL>
+__device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[RPT],
+                                           const int (&moff)[LBL ? RPT : 1], PanelShared<NT / 64, W> &sh,
+                                           int wave_u, int c0, bool wave_active, bool &singular, PanelGroup &pg,
+                                           float *mtp, int mtld)
 {
     constexpr int par = R & 1;
     const int slot = c0 + R;
@@ -372,6 +477,29 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
     float col[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) col[k] = a[k][R];
+    // the multiplier column of this step (mat_inv_32.cpp:30: what fixColumn reads before it overwrites the column);
+    // the pivot row's own entry is the pivot
+    // One store per step, fire and forget -- written so that NOTHING of it lives in vector registers across the
+    // steps: the base is scalar (global_store ... saddr form), the 32-bit lane offset is recomputed from the lane id
+    // (fused instances: one kept offset per row).  A pointer kept in VGPRs is the first thing the 128-VGPR instances
+    // spill, and its reload's s_waitcnt vmcnt(0) then waits for the previous step's store to be acknowledged by the
+    // memory system: +0.9 us per pivot step (measured: 28.5 -> 43 us per 16-step launch).
+    if constexpr (LBL) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) mt_store<1>(mtp + (size_t)R * mtld, (unsigned)moff[k] * 4u, col[k]);
+    } else {
+        constexpr int V = RPT < 4 ? RPT : 4;
+        typedef float mvecV __attribute__((ext_vector_type(V)));
+        const unsigned voff = (unsigned)(wave_u * 64 + lane) * (4u * V);
+#pragma unroll
+        for (int g = 0; g < RPT / V; ++g) {
+            mvecV v;
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] = col[g * V + j];
+            if constexpr (V == 1) mt_store<1>(mtp + (size_t)R * mtld + g * (V * NT), voff, col[g]);
+            else mt_store<V>(mtp + (size_t)R * mtld + g * (V * NT), voff, v);
+        }
+    }
     int own_lane = -1, own_k = 0;
     bool cand_bad = false;  // this wave's candidate has a zero / NaN / infinite pivot entry
     float qv = 0.0f;        // lanes 0..W-1: this wave's candidate row, normalised (kept for the export if it wins)
@@ -552,12 +680,13 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
     MI32_PSTAMP(pg.tag_base, 3 + R);
 }
 
-template <int NT, int RPT, int W, bool MULTI, int... Rs>
-__device__ __forceinline__ void panel_steps(float (&a)[RPT][W], unsigned (&npl)[RPT], PanelShared<NT / 64, W> &sh,
+template <int NT, int RPT, int W, bool MULTI, bool LBL, int... Rs>
+__device__ __forceinline__ void panel_steps(float (&a)[RPT][W], unsigned (&npl)[RPT],
+                                            const int (&moff)[LBL ? RPT : 1], PanelShared<NT / 64, W> &sh,
                                             int wave_u, int c0, bool wave_active, bool &singular, PanelGroup &pg,
-                                            std::integer_sequence<int, Rs...>)
+                                            float *mtp, int mtld, std::integer_sequence<int, Rs...>)
 {
-    (panel_step<NT, RPT, W, Rs, MULTI>(a, npl, sh, wave_u, c0, wave_active, singular, pg), ...);
+    (panel_step<NT, RPT, W, Rs, MULTI, LBL>(a, npl, moff, sh, wave_u, c0, wave_active, singular, pg, mtp, mtld), ...);
 }
 
 // Everything one fused sub-panel launch needs (passed by value).
@@ -572,13 +701,19 @@ struct SubpanelArgs {
     int row_lo;    // the workgroup holds the rows [row_lo, np) of its input order
     int first_in_block;
     const float *pt_in;      // Pt_s: this sub-panel's columns, updates up to s-2 applied, order after s-2
-    const float *gt_prev;    // Gt_{s-1}, same order
+    const float *mt_prev;    // Mt_{s-1}: the multipliers of sub-panel s-1, same order
     float *gt_out;           // Gt_s, order after s-1
+    float *mt_out;           // Mt_s: the multipliers of this sub-panel's W steps (fused: order after s-1; else slab order = the same)
+    size_t mtstride; int mtld;
+    const int *submap_prev;  // submap of sub-panel s-1: position after s-1 -> index in order after s-2
     const int *invsub_prev;  // index in order after s-2 -> position after s-1 (the row's label at entry)
     int *submap_out;         // position after s -> index in order after s-1
     int *invsub_out;         // its inverse
-    int *rowsrc, *orig;
-    float *aux_out;          // [2][kMaxW*kMaxW] per matrix: normalised pivot rows of s; pivot rows of s-1 x columns of s
+    const int *rowsrc_in;    // position after s-1 -> row index at the start of the block
+    int *rowsrc_out;         // the same after s (fused blocks: the other buffer -- update(s-1) still reads rowsrc_in)
+    int *rowsrc_alt;         // fused blocks, first sub-panel: the second buffer, whose rows above the block are set too
+    int *orig;
+    float *aux_out;          // [kAuxFloats] per matrix: normalised pivot rows of s; U_{s-1} x columns of s
     int *status;
     const int *guard;        // non-null for plans with shared panels: status words; a matrix flagged
                              // MI32_RUNTIME_ERROR (a panel lost a partner: its row maps are not to be trusted)
@@ -595,6 +730,10 @@ struct SubpanelArgs {
     const float *x;  // working copy in order after t-1
     float *y;        // working copy written in order after t
     const float *u_gt;     // Gt_t
+    const float *u_mt;     // Mt_t
+    const int *u_rowsrc;   // position after t -> row index at the start of the block
+    float *u_mf;           // the block's negated multipliers by block-start row index, [np][mf_ld]
+    size_t mfstride; int mf_ld;
     const int *u_submap;   // submap_t
     const float *u_pt_in;  // Pt_t (for the rows above the block)
     const float *u_aux;    // aux_t
@@ -631,6 +770,8 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     const int row_lo = A.row_lo + (MULTI ? grp * (NT * RPT) : 0);  // first row THIS workgroup holds
     const float *pt = A.pt_in + (size_t)b * A.tstride;
     const int *invsub_prev = A.invsub_prev + (size_t)b * np;
+    float *mt = A.mt_out + (size_t)b * A.mtstride;
+    const int mtld = A.mtld;
     if (tid < W) sh.key[tid] = 0ull;
     if (tid == 0) sh.lost = 0;
     MI32_PSTAMP(A.tag_base, 0);
@@ -665,48 +806,69 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     }
     // the row maps this workgroup will permute: fetched now (by label), so their latency hides behind the
     // steps, and parked in thread-private LDS slots (the 1024-thread instances have no registers to spare)
-    int *rowsrc = A.rowsrc + (size_t)b * np;
+    const int *rowsrc_in = A.rowsrc_in + (size_t)b * np;
+    int *rowsrc = A.rowsrc_out + (size_t)b * np;
     int *orig = A.orig + (size_t)b * np;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int row = row_lo + panel_row<NT, RPT>(tid, k);
         const int p0 = (int)(npl[k] ^ (unsigned)((int)npl[k] >> 31));
-        s_park[k * NT + tid] = (A.first_in_block || row >= np) ? p0 : rowsrc[p0];  // composite map so far
+        s_park[k * NT + tid] = (A.first_in_block || row >= np) ? p0 : rowsrc_in[p0];  // composite map so far
         s_park[(RPT + k) * NT + tid] = row < np ? orig[p0] : 0;
     }
     // rows above the block keep their place: identity entries in the maps the update kernels read
-    if (A.first_in_block && grp == 0)
+    if (A.first_in_block && grp == 0) {
         for (int i = tid; i < row_lo; i += NT) rowsrc[i] = i;
+        if (A.rowsrc_alt != nullptr) {
+            int *alt = A.rowsrc_alt + (size_t)b * np;
+            for (int i = tid; i < row_lo; i += NT) alt[i] = i;
+        }
+    }
 
 #ifdef MI32_PANEL_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     MI32_PSTAMP(A.tag_base, 1);
     if (has_prev) {
-        // -- update(s-1) on this sub-panel's columns, which nobody has applied yet:
-        //      a[row][c] = (row is a pivot row of s-1 ? 0 : a[row][c]) + sum_k G_{s-1}[row][k] * B[k][c],
-        //    B[k][:] = the pivot row of step k of s-1 as it stands in this panel's input, i.e. W of the rows this
-        //    workgroup holds.  One fmaf chain per element, k ascending, starting from the old value: bit for
-        //    bit what the MFMA in-block update computes for every other column.
+        // -- update(s-1) on this sub-panel's columns, which nobody has applied yet: the W pivot steps of s-1 as
+        //    every column outside that sub-panel sees them (strip_step above).  First the strip on the W pivot rows
+        //    of s-1, which this workgroup holds (one wave: W columns x 4 lanes); then every other row takes
+        //      a[row][c] = fmaf(-f_m[row], u_m[c], a[row][c]),  m ascending
+        //    -- one fmaf per element and step from the old value: the reference's own order (mat_inv_32.cpp:28-38).
+        constexpr int CPT = W / 4;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int rel = (int)npl[k] - A.c0_prev;  // dead rows carry their position itself
             if ((unsigned)rel < (unsigned)W && row_lo + panel_row<NT, RPT>(tid, k) < np) {
 #pragma unroll
-                for (int c = 0; c < W; ++c) {
-                    sh.bprev[rel][c] = a[k][c];
-                    a[k][c] = 0.0f;
-                }
+                for (int c = 0; c < W; ++c) sh.bprev[rel][c] = a[k][c];
             }
         }
+        {   // the multipliers of those W rows in the W steps of s-1, negated, [step][row]: Mt_{s-1} is stored by the
+            // rows' labels at the entry of panel(s-1), submap_{s-1} says which label the pivot row of each step had
+            const float *mtp = A.mt_prev + (size_t)b * A.mtstride;
+            const int *smp = A.submap_prev + (size_t)b * np;
+            for (int i = tid; i < W * W; i += NT)
+                sh.lt[i % W][i / W] = -mtp[(size_t)(i % W) * mtld + smp[A.c0_prev + i / W]];
+        }
         __syncthreads();
-        const float *gtp = A.gt_prev + (size_t)b * A.tstride;
+        if (tid < 4 * W) {
+            const int c = tid >> 2, g = tid & 3;
+            float x[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) x[j] = sh.bprev[CPT * g + j][c];
+            strip_steps<W>(x, &sh.lt[0][0], W + 4, g, &sh.uprev[0][c], W, std::make_integer_sequence<int, W>{});
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) sh.bprev[CPT * g + j][c] = x[j];
+        }
+        __syncthreads();
+        const float *mtp = A.mt_prev + (size_t)b * A.mtstride;
 #ifndef MI32_PRO_REGS
-#define MI32_PRO_REGS 32
+#define MI32_PRO_REGS 16  // (32: hipcc hoists every LDS read of the round and spills them -- 892 B of scratch per lane in the 1024 x 2 instance)
 #endif
         constexpr int KC = (MI32_PRO_REGS / RPT) < 1 ? 1 : ((MI32_PRO_REGS / RPT) > W ? W : (MI32_PRO_REGS / RPT));  // k's per round of loads
         // a ROLLED loop over the rounds: unrolled, hipcc hoists every round's loads to the top and the whole of
-        // G_{s-1} (RPT * W registers) is live beside the slab
+        // Mt_{s-1} (RPT * W registers) is live beside the slab
 #pragma unroll 1
         for (int k0 = 0; k0 < W; k0 += KC) {
             vecV gv[KC][RPT / V];
@@ -715,32 +877,60 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
 #pragma unroll
                 for (int g = 0; g < RPT / V; ++g) {
                     const int row = row_lo + panel_row<NT, RPT>(tid, g * V);
-                    gv[kk][g] = (row < np) ? *reinterpret_cast<const vecV *>(gtp + (size_t)(k0 + kk) * np + row)
+                    gv[kk][g] = (row < np) ? *reinterpret_cast<const vecV *>(mtp + (size_t)(k0 + kk) * mtld + row)
                                            : (vecV)(0.0f);
                 }
 #pragma unroll
             for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
                 for (int c4 = 0; c4 < W; c4 += 4) {
-                    const float4 bq = *reinterpret_cast<const float4 *>(&sh.bprev[k0 + kk][c4]);
+                    const float4 bq = *reinterpret_cast<const float4 *>(&sh.uprev[k0 + kk][c4]);
 #pragma unroll
                     for (int g = 0; g < RPT / V; ++g)
 #pragma unroll
                         for (int j = 0; j < V; ++j) {
-                            const float gval = gv[kk][g][j];
-                            a[g * V + j][c4 + 0] = __builtin_fmaf(gval, bq.x, a[g * V + j][c4 + 0]);
-                            a[g * V + j][c4 + 1] = __builtin_fmaf(gval, bq.y, a[g * V + j][c4 + 1]);
-                            a[g * V + j][c4 + 2] = __builtin_fmaf(gval, bq.z, a[g * V + j][c4 + 2]);
-                            a[g * V + j][c4 + 3] = __builtin_fmaf(gval, bq.w, a[g * V + j][c4 + 3]);
+                            const float nf = -gv[kk][g][j];
+                            a[g * V + j][c4 + 0] = __builtin_fmaf(nf, bq.x, a[g * V + j][c4 + 0]);
+                            a[g * V + j][c4 + 1] = __builtin_fmaf(nf, bq.y, a[g * V + j][c4 + 1]);
+                            a[g * V + j][c4 + 2] = __builtin_fmaf(nf, bq.z, a[g * V + j][c4 + 2]);
+                            a[g * V + j][c4 + 3] = __builtin_fmaf(nf, bq.w, a[g * V + j][c4 + 3]);
                         }
                 }
+        }
+        // the pivot rows of s-1 themselves: what the strip left
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int rel = (int)npl[k] - A.c0_prev;
+            if ((unsigned)rel < (unsigned)W && row_lo + panel_row<NT, RPT>(tid, k) < np) {
+#pragma unroll
+                for (int c = 0; c < W; ++c) a[k][c] = sh.bprev[rel][c];
+            }
         }
     }
     bool singular = false;
     __syncthreads();  // sh.key[] zeroed before any wave's first atomicMax; all map reads issued
     PanelGroup pg = {A.ngroups, grp, A.xch + (size_t)b * kXchGranules, A.tag_base, false};
     MI32_PSTAMP(A.tag_base, 2);
-    panel_steps<NT, RPT, W, MULTI>(a, npl, sh, wave_u, c0, true, singular, pg, std::make_integer_sequence<int, W>{});
+    // Mt_s: by the rows' labels at entry (order after s-1, what update(s) and the next fused panel index it by).
+    // Unfused panels hold their rows in that very order: this lane's first slot in row 0 of Mt (rows beyond np land
+    // in the padding of the mtld-wide rows).  Fused panels hold them in the order after s-2: one offset per row.
+    int moff[FUSED ? RPT : 1];
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int g = 0; g < RPT / V; ++g) {
+            const int row = row_lo + panel_row<NT, RPT>(tid, g * V);
+#pragma unroll
+            for (int j = 0; j < V; ++j) moff[g * V + j] = row + j;  // rows beyond np: a slot in the row's padding
+            if (has_prev && row < np) {
+                const ivecV p0 = *reinterpret_cast<const ivecV *>(invsub_prev + row);
+#pragma unroll
+                for (int j = 0; j < V; ++j) moff[g * V + j] = p0[j];
+            }
+        }
+    }
+    float *mt_lane = FUSED ? mt : mt + row_lo;  // wave-uniform; the lane's part is added by the store
+    panel_steps<NT, RPT, W, MULTI, FUSED>(a, npl, moff, sh, wave_u, c0, true, singular, pg, mt_lane, mtld,
+                                          std::make_integer_sequence<int, W>{});
     int pos[RPT];  // final position of every register row
 #pragma unroll
     for (int k = 0; k < RPT; ++k) pos[k] = (int)(npl[k] ^ (unsigned)((int)npl[k] >> 31));
@@ -749,11 +939,11 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     //    pivot rows of s-1 restricted to this sub-panel's columns
     __syncthreads();
     MI32_PSTAMP(A.tag_base, 48);
-    float *aux = A.aux_out + (size_t)b * (2 * kMaxW * kMaxW);
+    float *aux = A.aux_out + (size_t)b * kAuxFloats;
     if (grp == 0)
         for (int i = tid; i < W * W; i += NT) {
             aux[i] = sh.prn_all[i / W][i % W];
-            if (has_prev) aux[kMaxW * kMaxW + i] = sh.bprev[i / W][i % W];
+            if (has_prev) aux[kMaxW * kMaxW + i] = sh.uprev[i / W][i % W];
         }
     // -- G_s by label at entry (order after s-1: what update(s) reads the working copy in); the row maps
     float *gt = A.gt_out + (size_t)b * A.tstride;
@@ -815,13 +1005,15 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
 
 // One pivot step of a row that is not a candidate, for the in-block update tiles: the row's BK panel entries
 // are spread over the 4 threads of a quad (BK/4 consecutive columns each); its current entry in column R
-// lives in thread R / (BK/4) and is broadcast with one quad_perm DPP move.
+// lives in thread R / (BK/4) and is broadcast with one quad_perm DPP move.  That entry is the row's multiplier of
+// the step (fm: kept by the thread that owns column R).
 template <int BK, int R>
-__device__ __forceinline__ void above_rows_step(float (&v)[BK / 4], const float *s_prn, int q4)
+__device__ __forceinline__ void above_rows_step(float (&v)[BK / 4], float (&fm)[BK / 4], const float *s_prn, int q4)
 {
     constexpr int CPT = BK / 4;
     constexpr int kQuad = (R / CPT) * 0x55;  // quad_perm:[q,q,q,q]
     const float f = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[R % CPT]), kQuad, 0xf, 0xf, false));
+    fm[R % CPT] = (q4 == R / CPT) ? f : fm[R % CPT];
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int c = q4 * CPT + j;
@@ -830,37 +1022,47 @@ __device__ __forceinline__ void above_rows_step(float (&v)[BK / 4], const float 
     }
 }
 template <int BK, int... Rs>
-__device__ __forceinline__ void above_rows_steps(float (&v)[BK / 4], const float *s_prn, int q4,
+__device__ __forceinline__ void above_rows_steps(float (&v)[BK / 4], float (&fm)[BK / 4], const float *s_prn, int q4,
                                                  std::integer_sequence<int, Rs...>)
 {
-    (above_rows_step<BK, Rs>(v, s_prn, q4), ...);
+    (above_rows_step<BK, Rs>(v, fm, s_prn, q4), ...);
 }
 
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 // ---- update(t): the in-block rank-W update on the fp32 matrix cores ---------------
-//   y[i][j] = (i in Ks ? 0 : x[map[i]][j]) + sum_k G_t[i][k] * x[map[c0+k]][j]
-// for the columns j of the block that are not sub-panel t's own, 64 x 64 tiles, 256 threads = 4 waves in
-// a 2x2 arrangement per tile (NG tiles per workgroup), one 32x32 MFMA tile per wave.  One accumulation
-// chain per output element, starting from the old value, k ascending: bit for bit the fmaf chain of
-// oracle/gj_oracle.c's blocked restatement.  The column-tile-0 workgroups also materialise G_t into
-// y[i][c0 + k] (row-major), where every later update expects it.
+// For the columns j of the block that are not sub-panel t's own, 64 x 64 tiles, 256 threads = 4 waves in a 2x2
+// arrangement per tile (NG tiles per workgroup), one 32x32 MFMA tile per wave:
+//   strip   : the tile's 64 columns of the W pivot rows of t run the W steps (strip_step): u_m[j] and the pivot
+//             rows' new values;
+//   update  : y[i][j] = x[map[i]][j] - sum_m f_m[i] * u_m[j] for every other row, ONE accumulation chain per output
+//             element starting from the old value, m ascending (v_mfma_f32_32x32x2_f32 with the old value as its
+//             C operand is that fmaf chain): exactly the operations the reference's step loop applies to the
+//             element, in its order (mat_inv_32.cpp:28-38,317-362) -- bit for bit oracle/gj_oracle.c's
+//             gjo_matrix_inv_32_inplace.
+// The column-tile-0 workgroups also materialise sub-panel t's own columns G_t into y[i][c0 + k] (row-major) and
+// the rows' negated multipliers into mf[block-start row][c0 - C0 + k], where the rank-bw update finds them.
 template <int BK>
 struct __attribute__((aligned(16))) UpdateTileShared {
     static constexpr int LDA = 64 + ((32 / BK) > 0 ? (32 / BK) : 1);
     static constexpr int LDB = 64 + 4;
-    float s_b[BK * LDB];     // pivot rows (through the row map) x 64 columns
+    static constexpr int LT = BK + 4;
+    float s_b[BK * LDB];     // pivot rows (through the row map) x 64 columns; after the strip: u_m
+    float s_xs[BK * LDB];    // the pivot rows after the W steps
+    float s_lt[BK * LT];     // -multipliers of the W pivot rows, [step][row]
     float s_prn[BK * BK];    // sub-panel t's normalised pivot rows
-    float s_bprev[BK * BK];  // sub-panel t-1's pivot rows restricted to sub-panel t's columns
-    float s_a[BK * LDA];     // G_t of the tile's rows, [k][row]
+    float s_bprev[BK * BK];  // u_m of sub-panel t-1 restricted to sub-panel t's columns
+    float s_a[BK * LDA];     // -multipliers of the tile's rows, [k][row]
     int s_map[64];
+    int s_pmap[BK];          // where the W pivot rows lie in the order before the sub-panel's swaps
+    int s_rs[64];            // the tile's rows' indices at the start of the block
 };
 
 template <int BK, int NG>
 __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u, unsigned char *smem)
 {
     typedef UpdateTileShared<BK> TS;
-    constexpr int LDA = TS::LDA, LDB = TS::LDB;
+    constexpr int LDA = TS::LDA, LDB = TS::LDB, LT = TS::LT;
     constexpr int CPT = BK / 4;
     const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
     TS &T = reinterpret_cast<TS *>(smem)[grp];
@@ -879,20 +1081,42 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
     const float *src = A.x + (size_t)b * A.mstride;
     float *dst = A.y + (size_t)b * A.mstride;
     const float *g = A.u_gt + (size_t)b * A.tstride;
+    const float *mt = A.u_mt + (size_t)b * A.mtstride;
+    const int mtld = A.mtld;
     const int *map = A.u_submap + (size_t)b * np;
     const bool some_above = row0 < A.u_above_hi;  // some of this tile's rows were not in panel(t)
 
+    // Two dependent rounds of global loads in all: the maps first, then everything they index (old values,
+    // multipliers, pivot rows) -- requested into registers back to back, before the first of them is needed.
     if (tid < 64) T.s_map[tid] = map[row0 + tid];
+    else if (tid < 64 + BK) T.s_pmap[tid - 64] = map[c0 + tid - 64];
+    else if (tid >= 128 && tid < 192) T.s_rs[tid - 128] = (A.u_rowsrc + (size_t)b * np)[row0 + tid - 128];
     if (some_above) {
-        const float *aux = A.u_aux + (size_t)b * (2 * kMaxW * kMaxW);
+        const float *aux = A.u_aux + (size_t)b * kAuxFloats;
         for (int i = tid; i < BK * BK; i += 256) {
             T.s_prn[i] = aux[i];
             if (A.u_has_prev) T.s_bprev[i] = aux[kMaxW * kMaxW + i];
         }
     }
     __syncthreads();
-
-    // accumulators start from the (row-mapped) old values; rows of the sub-panel's pivots start from 0
+    // (1) the W pivot rows' own multipliers: Mt_t[step][index of the row of step kk in order after t-1]
+    constexpr int NLT = (BK * BK + 255) / 256;
+    float lval[NLT];
+#pragma unroll
+    for (int q = 0; q < NLT; ++q) {
+        const int i = tid + q * 256;
+        lval[q] = (i < BK * BK) ? mt[(size_t)(i % BK) * mtld + T.s_pmap[i / BK]] : 0.0f;
+    }
+    // (2) the W pivot rows (through the row map) x 64 columns
+    constexpr int NBQ = (BK * 16 + 255) / 256;
+    float4 bq[NBQ];
+#pragma unroll
+    for (int q = 0; q < NBQ; ++q) {
+        const int idx = tid + q * 256;
+        if (idx < BK * 16)
+            bq[q] = *reinterpret_cast<const float4 *>(src + (size_t)T.s_pmap[idx / 16] * ld + col0 + (idx % 16) * 4);
+    }
+    // (3) the accumulators start from the (row-mapped) old values
     float16v acc;
     const int lcol = lane & 31;
     const int lhalf = lane >> 5;
@@ -901,34 +1125,41 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int lr = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-            const int grow = row0 + lr;
-            const bool in_block = (grow >= c0 && grow < c0 + BK);
-            acc[reg] = in_block ? 0.0f : src[(size_t)T.s_map[lr] * ld + col];
+            acc[reg] = src[(size_t)T.s_map[lr] * ld + col];
         }
     }
     {
-        // stage A = G_t, [k][row]; 4 threads per row, BK/4 columns each.
-        //  * rows that were in panel(t): its compact output gt[k][map[row]];
-        //  * rows above (never candidates, never moved): their G_t is the row's W entries of the panel input
-        //    Pt_t, brought up to date with update(t-1) where that was still pending (the chain of the panel
-        //    prologue: old value + sum_k G_{t-1}[row][k] * Bprev[k][c], G_{t-1} as materialised in x), then
-        //    taken through the W pivot steps with the exported normalised pivot rows -- fixColumn
-        //    (mat_inv_32.cpp:28-38) on one row, the very fmaf sequence the panel applies to a dead row.
+        // (4) stage A = the tile's rows' multipliers, negated, [k][row]; 4 threads per row, BK/4 columns each.
+        //  * rows that were in panel(t): its compact output mt[k][map[row]] (and gt[k][map[row]] = the row's new
+        //    entries in sub-panel t's own columns);
+        //  * rows above (never candidates, never moved): the row's W entries of the panel input Pt_t, brought up
+        //    to date with update(t-1) where that was still pending (the chain of the panel prologue: old value -
+        //    sum_m f_m[row] * u_m[c], f_m as materialised in mf), then taken through the W pivot steps with the
+        //    exported normalised pivot rows -- fixColumn (mat_inv_32.cpp:28-38) on one row, the very fmaf
+        //    sequence the panel applies to a dead row; the entry the row holds in the pivot column when a step
+        //    runs is its multiplier.
         const int rr = tid >> 2, q4 = tid & 3;
         const int grow = row0 + rr;
-        float v[CPT];
+        float v[CPT], fm[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { v[j] = 0.0f; fm[j] = 0.0f; }
+        float *mfrow = A.u_mf + (size_t)b * A.mfstride + (size_t)T.s_rs[rr] * A.mf_ld + (c0 - A.C0);
         if (grow >= A.u_above_hi) {
 #pragma unroll
-            for (int j = 0; j < CPT; ++j) v[j] = g[(size_t)(q4 * CPT + j) * np + T.s_map[rr]];
+            for (int j = 0; j < CPT; ++j) fm[j] = mt[(size_t)(q4 * CPT + j) * mtld + T.s_map[rr]];
+            if (tx == 0) {
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) v[j] = g[(size_t)(q4 * CPT + j) * np + T.s_map[rr]];
+            }
         } else {
             const float *pt_in = A.u_pt_in + (size_t)b * A.tstride;
 #pragma unroll
             for (int j = 0; j < CPT; ++j) v[j] = pt_in[(size_t)(q4 * CPT + j) * np + grow];
             if (A.u_has_prev) {
-                const float *gp = src + (size_t)grow * ld + (c0 - BK);  // G_{t-1}[grow][0..BK): same width, same block
+                const float *mp = mfrow - BK;  // -f_m of sub-panel t-1 for this row: same width, same block
 #pragma unroll
                 for (int k4 = 0; k4 < BK; k4 += 4) {
-                    const float4 gq = *reinterpret_cast<const float4 *>(gp + k4);
+                    const float4 gq = *reinterpret_cast<const float4 *>(mp + k4);
                     const float gk4[4] = {gq.x, gq.y, gq.z, gq.w};
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
@@ -937,32 +1168,40 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
                             v[j] = __builtin_fmaf(gk4[kk], T.s_bprev[(k4 + kk) * BK + q4 * CPT + j], v[j]);
                 }
             }
-            above_rows_steps<BK>(v, T.s_prn, q4, std::make_integer_sequence<int, BK>{});
+            above_rows_steps<BK>(v, fm, T.s_prn, q4, std::make_integer_sequence<int, BK>{});
+        }
+        // everything requested; now into LDS
+#pragma unroll
+        for (int q = 0; q < NLT; ++q) {
+            const int i = tid + q * 256;
+            if (i < BK * BK) T.s_lt[(i % BK) * LT + i / BK] = -lval[q];
         }
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) T.s_a[(q4 * CPT + j) * LDA + rr] = v[j];
-    }
-    // stage B: BK pivot rows (through the row map) x 64 columns
+        for (int q = 0; q < NBQ; ++q) {
+            const int idx = tid + q * 256;
+            if (idx < BK * 16) *reinterpret_cast<float4 *>(&T.s_b[(idx / 16) * LDB + (idx % 16) * 4]) = bq[q];
+        }
 #pragma unroll
-    for (int q = 0; q < (BK * 16 + 255) / 256; ++q) {
-        const int idx = tid + q * 256;
-        if (idx < BK * 16) {
-            const int kk = idx / 16, c4 = (idx % 16) * 4;
-            const int brow = map[c0 + kk];
-            *reinterpret_cast<float4 *>(&T.s_b[kk * LDB + c4]) =
-                *reinterpret_cast<const float4 *>(src + (size_t)brow * ld + col0 + c4);
+        for (int j = 0; j < CPT; ++j) T.s_a[(q4 * CPT + j) * LDA + rr] = -fm[j];
+        if (tx == 0) {  // materialise: G_t into the row-major working copy, -f into the block's multiplier matrix
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                dst[(size_t)grow * ld + c0 + q4 * CPT + j] = v[j];
+                mfrow[q4 * CPT + j] = -fm[j];
+            }
         }
     }
     __syncthreads();
-    // materialise G_t into the row-major working copy (column tile 0 only)
-    if (tx == 0) {
-        for (int idx = tid; idx < 64 * (BK / 4); idx += 256) {
-            const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-            *reinterpret_cast<float4 *>(dst + (size_t)(row0 + rr) * ld + c0 + k4) =
-                make_float4(T.s_a[(k4 + 0) * LDA + rr], T.s_a[(k4 + 1) * LDA + rr], T.s_a[(k4 + 2) * LDA + rr],
-                            T.s_a[(k4 + 3) * LDA + rr]);
-        }
+    {   // the strip: column tid >> 2 of the W pivot rows, rows CPT * (tid & 3) ... in this lane
+        const int c = tid >> 2, q4 = tid & 3;
+        float x[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) x[j] = T.s_b[(CPT * q4 + j) * LDB + c];
+        strip_steps<BK>(x, T.s_lt, LT, q4, &T.s_b[c], LDB, std::make_integer_sequence<int, BK>{});
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) T.s_xs[(CPT * q4 + j) * LDB + c] = x[j];
     }
+    __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
         const float af = T.s_a[(kk + lhalf) * LDA + wr * 32 + lcol];
@@ -972,6 +1211,14 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
     {
         const int col = col0 + wc * 32 + lcol;
         if (!(col >= c0 && col < c0 + BK)) {  // sub-panel t's own columns hold G_t, not an update result
+            // the W pivot rows of t are rows c0 .. c0+W-1 of the new order: they take what the strip left
+            if (row0 + wr * 32 < c0 + BK && row0 + wr * 32 + 32 > c0) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rel = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf - c0;
+                    if ((unsigned)rel < (unsigned)BK) acc[reg] = T.s_xs[rel * LDB + wc * 32 + lcol];
+                }
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int grow = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
@@ -1027,15 +1274,196 @@ __global__ __launch_bounds__(256) void gj_inblock_update_kernel(SubpanelArgs A)
     inblock_update_body<W, 1>(A, (int)blockIdx.x, upd_smem);
 }
 
+// ---- the block's pivot-row strip: what every column outside the block sees of its kb pivot steps -----
+// One workgroup per CT-column tile outside the block keeps the kb pivot rows x CT columns in LDS and runs the
+// block's kb pivot steps on them, 16 at a time: strip_step on the 16 pivot rows of the group (u_m, 16 dependent
+// IEEE divisions), then every other pivot row takes its 16 fmaf (one v_mfma_f32_32x32x2_f32 chain with the old
+// value as C operand, k ascending).  Out: ub[m][j] = u_m[j] -- the pivot row of step m as fixColumn saw it
+// (mat_inv_32.cpp:28-38), the B operand of the rank-bw update -- and the kb pivot rows after the block's last
+// step, written to rows [C0, C0 + kb) of the new working copy (and to the next block's compact panel inputs).
+// mf[q][m] = -f_m of the row whose index at the start of the block was q (own step: -pivot); map = rowsrc.
+template <int CT>
+constexpr size_t block_strip_lds_bytes(int kb)
+{
+    return ((size_t)kb * (CT + 4) + (size_t)16 * (kb + 4) + (size_t)2 * 16 * (CT + 4)) * sizeof(float) + (size_t)kb * sizeof(int);
+}
+static constexpr int kStripThreads = 1024;  // 16 waves: one 32 x 32 tile of the pivot rows each (kb 256, CT 64)
+template <int CT>
+__global__ __launch_bounds__(kStripThreads) void gj_block_strip_kernel(const float *__restrict__ src_all, float *__restrict__ dst_all,
+                                                              size_t mstride, int np, int ld,
+                                                              const float *__restrict__ mf_all, size_t mfstride, int mf_ld,
+                                                              float *__restrict__ ub_all, size_t ubstride, int C0, int kb,
+                                                              const int *__restrict__ map_all, int col_lo, int col_hi,
+                                                              int inside, PanelExport ex, size_t tstride,
+                                                              const int *__restrict__ guard)
+{
+    extern __shared__ __attribute__((aligned(16))) float bs_smem[];
+    constexpr int LDX = CT + 4;
+    constexpr int NT = kStripThreads;
+    const int LT = kb + 4;
+    float *s_x = bs_smem;                  // [kb][LDX]  the pivot rows
+    float *s_lt = s_x + (size_t)kb * LDX;  // [16][LT]   -f of the current 16 steps, [step][pivot row]
+    float *s_u = s_lt + 16 * LT;           // [2][16][LDX]  u_m of the current 16 steps (and of the previous 16)
+    int *s_q = reinterpret_cast<int *>(s_u + 2 * 16 * LDX);  // [kb] block-start row index of every pivot row
+
+    const int b = blockIdx.y;
+    if (matrix_given_up(guard, b)) return;
+    const int col0 = blockIdx.x * CT;
+    if (col0 >= C0 && col0 < C0 + kb) return;  // the block's own columns are up to date already
+    const bool in_range = (col0 >= col_lo && col0 < col_hi);
+    if (in_range != (inside != 0)) return;     // the look-ahead splits the columns between two launches
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const float *src = src_all + (size_t)b * mstride;
+    float *dst = dst_all + (size_t)b * mstride;
+    const float *mf = mf_all + (size_t)b * mfstride;
+    float *ub = ub_all + (size_t)b * ubstride;
+    const int *map = map_all + (size_t)b * np;
+
+    for (int i = tid; i < kb; i += NT) s_q[i] = map[C0 + i];
+    __syncthreads();
+    for (int idx = tid; idx < kb * (CT / 4); idx += NT) {
+        const int k = idx / (CT / 4), c4 = (idx % (CT / 4)) * 4;
+        *reinterpret_cast<float4 *>(&s_x[k * LDX + c4]) =
+            *reinterpret_cast<const float4 *>(src + (size_t)s_q[k] * ld + col0 + c4);
+    }
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    // the multipliers of 16 steps, all kb pivot rows: requested one round ahead (registers), so that a round is the
+    // strip and the update, not a dependent global round trip on top
+    constexpr int NL = kMaxBW * 4 / NT;
+    float4 lreg[NL];
+    auto load_l = [&](int s16) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < kb * 4)
+                lreg[i] = *reinterpret_cast<const float4 *>(mf + (size_t)s_q[idx >> 2] * mf_ld + s16 + (idx & 3) * 4);
+        }
+    };
+    auto store_l = [&]() {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < kb * 4) {
+                const int k = idx >> 2, m4 = (idx & 3) * 4;
+                s_lt[(m4 + 0) * LT + k] = lreg[i].x;
+                s_lt[(m4 + 1) * LT + k] = lreg[i].y;
+                s_lt[(m4 + 2) * LT + k] = lreg[i].z;
+                s_lt[(m4 + 3) * LT + k] = lreg[i].w;
+            }
+        }
+    };
+    // u_m of 16 steps -> the rank-bw update's B operand.  Stored one round late, in front of the next request for
+    // multipliers: a wave's memory operations complete in order, and the wait for those multipliers at the end of a
+    // round must not have to wait for a store issued a moment ago to be acknowledged.
+    auto store_u = [&](int s16) {
+        const float *su = s_u + ((s16 >> 4) & 1) * 16 * LDX;
+        for (int idx = tid; idx < 16 * (CT / 4); idx += NT) {
+            const int m = idx / (CT / 4), c4 = (idx % (CT / 4)) * 4;
+            *reinterpret_cast<float4 *>(ub + (size_t)(s16 + m) * np + col0 + c4) =
+                *reinterpret_cast<const float4 *>(&su[m * LDX + c4]);
+        }
+    };
+    load_l(0);
+    store_l();
+    for (int s16 = 0; s16 < kb; s16 += 16) {
+        float *su = s_u + ((s16 >> 4) & 1) * 16 * LDX;
+        if (s16 > 0) store_u(s16 - 16);
+        if (s16 + 16 < kb) load_l(s16 + 16);
+        __syncthreads();  // s_lt complete; s_x complete (first round: loaded, later: the previous round's update)
+        if (tid < 4 * CT) {
+            const int c = tid >> 2, q4 = tid & 3;
+            float x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = s_x[(s16 + 4 * q4 + j) * LDX + c];
+            strip_steps<16>(x, s_lt + s16, LT, q4, &su[c], LDX, std::make_integer_sequence<int, 16>{});
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_x[(s16 + 4 * q4 + j) * LDX + c] = x[j];
+        }
+        __syncthreads();
+        // every other pivot row: x[k][c] = fmaf(-f_m[k], u_m[c], x[k][c]), m ascending, 32 x 32 tiles over the waves
+        const int ntiles = (kb / 32) * (CT / 32);
+        for (int t = wave; t < ntiles; t += NT / 64) {
+            const int rt = t / (CT / 32), ctl = t % (CT / 32);
+            float16v acc;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                acc[reg] = s_x[(rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf) * LDX + ctl * 32 + lcol];
+#pragma unroll
+            for (int kk = 0; kk < 16; kk += 2) {
+                const float af = s_lt[(kk + lhalf) * LT + rt * 32 + lcol];
+                const float bf = su[(kk + lhalf) * LDX + ctl * 32 + lcol];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                if (r < s16 || r >= s16 + 16) s_x[r * LDX + ctl * 32 + lcol] = acc[reg];  // not the group's own rows
+            }
+        }
+        __syncthreads();  // before s_lt is overwritten and s_x is read again
+        if (s16 + 16 < kb) store_l();
+    }
+    store_u(kb - 16);
+    // the pivot rows are rows C0 .. C0+kb-1 of the new order
+    for (int idx = tid; idx < kb * (CT / 4); idx += NT) {
+        const int k = idx / (CT / 4), c4 = (idx % (CT / 4)) * 4;
+        *reinterpret_cast<float4 *>(dst + (size_t)(C0 + k) * ld + col0 + c4) =
+            *reinterpret_cast<const float4 *>(&s_x[k * LDX + c4]);
+    }
+    // ... and their entries in the next block's first sub-panels go to the compact panel inputs as well
+    if (col0 + CT > ex.col && col0 < ex.col + ex.w * ex.count) {
+        for (int idx = tid; idx < CT * (kb / 4); idx += NT) {
+            const int c = idx / (kb / 4), k4 = (idx % (kb / 4)) * 4;
+            panel_export_store4(ex, tstride, b, np, col0 + c, C0 + k4, s_x[(k4 + 0) * LDX + c], s_x[(k4 + 1) * LDX + c],
+                                s_x[(k4 + 2) * LDX + c], s_x[(k4 + 3) * LDX + c]);
+        }
+    }
+}
+
+// Gk[k][row] = mf[map[row]][k], k < kdim: the block's negated multipliers, transposed and in the new row order
+// (A operand of the rank-bw update); 64 x 64 tiles through LDS, both global sides coalesced.
+__global__ __launch_bounds__(256) void gj_mult_transpose_kernel(const float *__restrict__ mf_all, size_t mfstride, int mf_ld,
+                                                                 int np, const int *__restrict__ map_all,
+                                                                 float *__restrict__ gk_all, size_t gkstride,
+                                                                 const int *__restrict__ guard)
+{
+    __shared__ float t[64][65];
+    __shared__ int s_q[64];
+    const int b = blockIdx.z;
+    if (matrix_given_up(guard, b)) return;
+    const int row0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const float *mf = mf_all + (size_t)b * mfstride;
+    float *gk = gk_all + (size_t)b * gkstride;
+    if (tid < 64) s_q[tid] = (map_all + (size_t)b * np)[row0 + tid];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (tid >> 4) + 16 * q, c4 = (tid & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(mf + (size_t)s_q[r] * mf_ld + k0 + c4);
+        t[r][c4] = v.x; t[r][c4 + 1] = v.y; t[r][c4 + 2] = v.z; t[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = (tid >> 4) + 16 * q, r4 = (tid & 15) * 4;
+        *reinterpret_cast<float4 *>(gk + (size_t)(k0 + k) * np + row0 + r4) =
+            make_float4(t[r4][k], t[r4 + 1][k], t[r4 + 2][k], t[r4 + 3][k]);
+    }
+}
+
 // ---- rank-k update of the next block's columns (look-ahead half (A) of a rank-bw update) -----
-//   dst[i][j] = (i in [c0,c0+kdim) ? 0 : src[map[i]][j]) + sum_k G[i][k] * src[map[c0+k]][j]
-// for the 64-column tiles starting at col_lo.  Same arithmetic as the rank-bw kernel of mi32_rank_bw.h (sum of
-// products from zero, k ascending, old value added last), on 64 x 64 tiles because the few columns of one block
-// would otherwise make too few workgroups; G is read from the row-major working copy.
+//   dst[i][j] = src[map[i]][j] - sum_m f_m[i] * u_m[j]    for the rows i outside the block
+// for the 64-column tiles starting at col_lo.  Same arithmetic as the rank-bw kernel of mi32_rank_bw.h (one fmaf
+// chain per element from the old value, m ascending), on 64 x 64 tiles because the few columns of one block would
+// otherwise make too few workgroups; -f is read from the block's multiplier matrix through the row map, u_m from ub.
 template <int BK>
 __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__restrict__ src_all,
                                                               float *__restrict__ dst_all,
-                                                              const float *__restrict__ g_all, size_t gstride,
+                                                              const float *__restrict__ mf_all, size_t mfstride, int mf_ld,
+                                                              const float *__restrict__ ub_all, size_t ubstride,
                                                               int np, int ld, size_t mstride, int c0, int kdim,
                                                               int col_lo, const int *__restrict__ map_all,
                                                               PanelExport ex, size_t tstride,
@@ -1048,7 +1476,6 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     __shared__ float s_a[BK * LDA];
     __shared__ __attribute__((aligned(16))) float s_b[BK * LDB];
     __shared__ int s_map[BM];
-    __shared__ int s_bmap[kMaxBW];  // the block's pivot rows: read once, not once per k-tile
 
     const int b = blockIdx.z;
     if (matrix_given_up(guard, b)) return;
@@ -1057,17 +1484,18 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int row0 = blockIdx.y * BM;
+    if (row0 >= c0 && row0 < c0 + kdim) return;  // the block's pivot rows: written by gj_block_strip_kernel
     const int col0 = col_lo + blockIdx.x * BN;
     const float *src = src_all + (size_t)b * mstride;
     float *dst = dst_all + (size_t)b * mstride;
-    const float *g = g_all + (size_t)b * gstride;
+    const float *mf = mf_all + (size_t)b * mfstride;
+    const float *ub = ub_all + (size_t)b * ubstride;
     const int *map = map_all + (size_t)b * np;
 
     for (int i = tid; i < BM; i += 256) s_map[i] = map[row0 + i];
-    for (int i = tid; i < kdim; i += 256) s_bmap[i] = map[c0 + i];
     __syncthreads();
 
-    float16v acc, cin;
+    float16v acc;
     const int lcol = lane & 31;
     const int lhalf = lane >> 5;
     {
@@ -1075,35 +1503,31 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int lr = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-            const int grow = row0 + lr;
-            const bool in_block = (grow >= c0 && grow < c0 + kdim);
-            cin[reg] = in_block ? 0.0f : src[(size_t)s_map[lr] * ld + col];
-            acc[reg] = 0.0f;
+            acc[reg] = src[(size_t)s_map[lr] * ld + col];
         }
     }
     for (int kt = 0; kt < kdim; kt += BK) {
-        // stage A: BM x BK of the row-major panel, transposed
+        // stage A: BM x BK of the row-major multiplier matrix (rows through the map), transposed
 #pragma unroll
         for (int q = 0; q < (BM * BK / 4 + 255) / 256; ++q) {
             const int idx = tid + q * 256;
             if (idx < BM * BK / 4) {
                 const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-                const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)(row0 + rr) * ld + c0 + kt + k4);
+                const float4 v = *reinterpret_cast<const float4 *>(mf + (size_t)s_map[rr] * mf_ld + kt + k4);
                 s_a[(k4 + 0) * LDA + rr] = v.x;
                 s_a[(k4 + 1) * LDA + rr] = v.y;
                 s_a[(k4 + 2) * LDA + rr] = v.z;
                 s_a[(k4 + 3) * LDA + rr] = v.w;
             }
         }
-        // stage B: BK pivot rows (through the row map) x BN columns
+        // stage B: BK rows of u x BN columns
 #pragma unroll
         for (int q = 0; q < (BK * BN / 4 + 255) / 256; ++q) {
             const int idx = tid + q * 256;
             if (idx < BK * BN / 4) {
                 const int kk = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
-                const int brow = s_bmap[kt + kk];
                 *reinterpret_cast<float4 *>(&s_b[kk * LDB + c4]) =
-                    *reinterpret_cast<const float4 *>(src + (size_t)brow * ld + col0 + c4);
+                    *reinterpret_cast<const float4 *>(ub + (size_t)(kt + kk) * np + col0 + c4);
             }
         }
         __syncthreads();
@@ -1117,17 +1541,15 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     }
     {
         const int col = col0 + wc * 32 + lcol;
-        float ov[16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int grow = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-            ov[reg] = acc[reg] + cin[reg];
-            dst[(size_t)grow * ld + col] = ov[reg];
+            dst[(size_t)grow * ld + col] = acc[reg];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            panel_export_store4(ex, tstride, b, np, col, row0 + wr * 32 + 8 * q + 4 * lhalf, ov[4 * q], ov[4 * q + 1],
-                                ov[4 * q + 2], ov[4 * q + 3]);
+            panel_export_store4(ex, tstride, b, np, col, row0 + wr * 32 + 8 * q + 4 * lhalf, acc[4 * q], acc[4 * q + 1],
+                                acc[4 * q + 2], acc[4 * q + 3]);
     }
 }
 
@@ -1229,6 +1651,9 @@ static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelA
     if (nt == T && rpt == R && w == WW && !fused) return launch_subpanel<T, R, WW, false>(A, nwgs, stream);
 #define MI32_SUBPANEL_FUSED(T, R, WW)                                                                  \
     if (nt == T && rpt == R && w == WW && fused) return launch_subpanel<T, R, WW, true>(A, nwgs, stream);
+#ifdef MI32_EXPERIMENT_MIN  // compile-time experiments (tools/build_check.sh): the two instances C1 runs most
+    MI32_SUBPANEL_CASE(1024, 4, 16) MI32_SUBPANEL_FUSED(1024, 2, 16)
+#else
     MI32_SUBPANEL_CASE(256, 1, 32) MI32_SUBPANEL_CASE(256, 1, 16) MI32_SUBPANEL_CASE(256, 1, 8) MI32_SUBPANEL_CASE(256, 1, 4)
     MI32_SUBPANEL_CASE(512, 1, 32) MI32_SUBPANEL_CASE(512, 2, 32) MI32_SUBPANEL_CASE(512, 4, 32)
     MI32_SUBPANEL_CASE(1024, 1, 32) MI32_SUBPANEL_CASE(1024, 2, 32)
@@ -1249,6 +1674,7 @@ static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelA
     MI32_SUBPANEL_FUSED(1024, 1, 8) MI32_SUBPANEL_FUSED(1024, 2, 8)
     MI32_SUBPANEL_FUSED(512, 1, 4) MI32_SUBPANEL_FUSED(512, 2, 4) MI32_SUBPANEL_FUSED(512, 4, 4)
     MI32_SUBPANEL_FUSED(1024, 1, 4) MI32_SUBPANEL_FUSED(1024, 2, 4)
+#endif
 #undef MI32_SUBPANEL_CASE
 #undef MI32_SUBPANEL_FUSED
     return hipErrorInvalidValue;
@@ -1308,6 +1734,10 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                                       (int)rank_bw2_lds_bytes<MI32_BW_BK>(kMaxBW));
             (void)hipFuncSetAttribute((const void *)gj_rank_bw2_persistent_kernel<MI32_BW_BK>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+            (void)hipFuncSetAttribute((const void *)gj_block_strip_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)block_strip_lds_bytes<64>(256));
+            (void)hipFuncSetAttribute((const void *)gj_block_strip_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)block_strip_lds_bytes<32>(kMaxBW));
             attr_set = true;
         }
     }
@@ -1323,7 +1753,8 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     int blk = 0, ev = 0;
     for (int C0 = 0; C0 < np; C0 += p.bw, ++blk) {
         const int kb = (C0 + p.bw <= np) ? p.bw : np - C0;
-        int *rowsrc = ws.rowsrc[blk & 1];
+        int **rsb = &ws.rowsrc[2 * (blk & 1)];
+        float *mf = ws.mf[blk & 1], *ub = ws.ub[blk & 1];
         const int w = p.wblk[blk];                                       // sub-panel width of this block
         const int w_next = (blk + 1 < p.nblk) ? p.wblk[blk + 1] : w;     // ... and of the next one
         const int S = kb / w;                                            // sub-panels of this block (even)
@@ -1337,6 +1768,8 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
             SubpanelArgs P = {};   // the panel half
             P.np = np; P.n = p.n; P.ld = p.ld; P.batch = batch;
             P.mstride = ws.mstride; P.tstride = ws.tstride;
+            P.mtstride = ws.mtstride; P.mtld = ws.mtld;
+            P.mfstride = ws.mfstride; P.mf_ld = p.bw;
             P.u_exp = no_export;
             P.guard = guard;
             SubpanelArgs U = P;    // the update half
@@ -1348,12 +1781,16 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 P.row_lo = P.has_prev ? P.c0_prev : P.c0;  // fused: the W pivot rows of s-1 are needed once more
                 P.first_in_block = (s == 0);
                 P.pt_in = ws.pt[s % 3];
-                P.gt_prev = ws.gt[(s + 1) & 1];
+                P.mt_prev = ws.mt[(s + 1) & 1];
                 P.gt_out = ws.gt[s & 1];
+                P.mt_out = ws.mt[s & 1];
+                P.submap_prev = ws.submap[(s + 1) & 1];
                 P.invsub_prev = ws.invsub[(s + 1) & 1];
                 P.submap_out = ws.submap[s & 1];
                 P.invsub_out = ws.invsub[s & 1];
-                P.rowsrc = rowsrc;
+                P.rowsrc_in = rsb[fused ? (s + 1) & 1 : 0];
+                P.rowsrc_out = rsb[fused ? s & 1 : 0];
+                P.rowsrc_alt = (fused && s == 0) ? rsb[1] : nullptr;
                 P.orig = ws.orig;
                 P.aux_out = ws.aux[s & 1];
                 P.status = d_status;
@@ -1371,6 +1808,9 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 U.C0 = C0; U.kb = kb;
                 U.x = x; U.y = y;
                 U.u_gt = ws.gt[t & 1];
+                U.u_mt = ws.mt[t & 1];
+                U.u_rowsrc = rsb[fused ? t & 1 : 0];
+                U.u_mf = mf;
                 U.u_submap = ws.submap[t & 1];
                 U.u_pt_in = ws.pt[t % 3];
                 U.u_aux = ws.aux[t & 1];
@@ -1383,6 +1823,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 SubpanelArgs A = P;  // one launch: panel(s) || update(s-1)
                 A.upd_on = U.upd_on; A.u_c0 = U.u_c0; A.u_has_prev = U.u_has_prev; A.u_above_hi = U.u_above_hi;
                 A.C0 = U.C0; A.kb = U.kb; A.x = U.x; A.y = U.y; A.u_gt = U.u_gt; A.u_submap = U.u_submap;
+                A.u_mt = U.u_mt; A.u_rowsrc = U.u_rowsrc; A.u_mf = U.u_mf;
                 A.u_pt_in = U.u_pt_in; A.u_aux = U.u_aux; A.u_exp = U.u_exp;
                 // a fused launch is accounted to the panel while there is one (it is the critical path)
                 ProfScope ps(prof, A.panel_on ? KC_PANEL : KC_UPDATE_IN, stream);
@@ -1399,11 +1840,12 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
             }
             if (s > 0) { float *t2 = x; x = y; y = t2; }
         }
-        // x now holds the block's G; every other column is still valid in `cur` only
+        // x now holds the block's own columns; every other column is still valid in `cur` only
         if (kb < np) {
             const int next = C0 + kb;  // first column of the next block
             const bool has_next = next < np;
             const int kb_next = has_next ? ((next + p.bw <= np) ? p.bw : np - next) : 0;
+            const int *rowsrc = rsb[fused ? (S - 1) & 1 : 0];  // position after the block -> row index at its start
             // the next block's first two sub-panels, fully updated, for its first two panels
             const PanelExport exn =
                 has_next ? PanelExport{ws.pt[0], ws.pt_bstride, next, w_next, (np - next) <= fused_rows ? 2 : 1} : no_export;
@@ -1413,45 +1855,57 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 pending_b = false;
             }
             const bool split_update = lookahead && has_next;
-            if (!split_update) {  // A operand of the rank-bw update: the block's panel, k-major (mi32_rank_bw.h)
-                ProfScope ps(prof, KC_TRANSPOSE, stream);
-                hipLaunchKernelGGL(gj_panel_transpose_kernel, dim3(np / 64, kb / 64, batch), dim3(256), 0, stream, x,
-                                   ws.mstride, np, p.ld, C0, ws.gk, ws.gkstride);
-            }
+            // the pivot-row strip of the columns [lo, hi) (inside) or of all columns but those (outside)
+            auto launch_strip = [&](hipStream_t st, int lo, int hi, int inside, const PanelExport &pe) {
+                ProfScope ps(prof, KC_STRIP, st);
+                if (kb <= 256)
+                    hipLaunchKernelGGL((gj_block_strip_kernel<64>), dim3(np / 64, batch), dim3(kStripThreads),
+                                       block_strip_lds_bytes<64>(kb), st, cur, oth, ws.mstride, np, p.ld, mf, ws.mfstride,
+                                       p.bw, ub, ws.gkstride, C0, kb, rowsrc, lo, hi, inside, pe, ws.tstride, guard);
+                else
+                    hipLaunchKernelGGL((gj_block_strip_kernel<32>), dim3(np / 32, batch), dim3(kStripThreads),
+                                       block_strip_lds_bytes<32>(kb), st, cur, oth, ws.mstride, np, p.ld, mf, ws.mfstride,
+                                       p.bw, ub, ws.gkstride, C0, kb, rowsrc, lo, hi, inside, pe, ws.tstride, guard);
+            };
+            auto launch_transpose = [&](hipStream_t st) {  // A operand of the rank-bw update, k-major (mi32_rank_bw.h)
+                ProfScope ps(prof, KC_TRANSPOSE, st);
+                hipLaunchKernelGGL(gj_mult_transpose_kernel, dim3(np / 64, kb / 64, batch), dim3(256), 0, st, mf,
+                                   ws.mfstride, p.bw, np, rowsrc, ws.gk, ws.gkstride, guard);
+            };
             if (split_update) {
                 {   // (A): the next block's columns, on the main stream; exports the next sub-panels
+                    launch_strip(stream, next, next + kb_next, 1, exn);
                     ProfScope ps(prof, KC_UPDATE_OUT, stream);
                     // small tiles: only kb_next columns, so 64x64 gives 4x the workgroups of 128x128
                     hipLaunchKernelGGL((gj_rank_update_kernel<32>), dim3(kb_next / 64, np / 64, batch), dim3(256), 0,
-                                       stream, cur, oth, x, ws.mstride, np, p.ld, ws.mstride, C0, kb, next, rowsrc, exn,
-                                       ws.tstride, guard);
+                                       stream, cur, oth, mf, ws.mfstride, p.bw, ub, ws.gkstride, np, p.ld, ws.mstride, C0, kb,
+                                       next, rowsrc, exn, ws.tstride, guard);
                 }
                 // (B): everything else, on the second stream, after this block's panel phase
                 ev = (ev + 1) % (ex.n_events / 2);
                 hipEvent_t e_panel = ex.events[ex.n_events / 2 + ev];
                 if ((e = hipEventRecord(e_panel, stream)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(ex.aux, e_panel, 0)) != hipSuccess) return e;
-                {   // only half (B) reads the transposed panel: its transposition stays off the main stream
-                    ProfScope ps(prof, KC_TRANSPOSE, ex.aux);
-                    hipLaunchKernelGGL(gj_panel_transpose_kernel, dim3(np / 64, kb / 64, batch), dim3(256), 0, ex.aux, x,
-                                       ws.mstride, np, p.ld, C0, ws.gk, ws.gkstride);
-                }
+                launch_strip(ex.aux, next, next + kb_next, 0, no_export);
+                launch_transpose(ex.aux);  // only half (B) reads the transposed multipliers: off the main stream
                 {
                     ProfScope ps(prof, KC_UPDATE_OUT, ex.aux);
                     // persistent flavour: aux_workgroups (< number of CUs) workgroups, with so much dynamic LDS
                     // that one CU holds at most one of them -> the remaining CUs stay free for the main stream
                     hipLaunchKernelGGL((gj_rank_bw2_persistent_kernel<MI32_BW_BK>), dim3(ex.aux_workgroups, batch),
-                                       dim3(256), lds_persistent, ex.aux, cur, oth, x, ws.mstride, ws.gk, ws.gkstride, np,
+                                       dim3(256), lds_persistent, ex.aux, cur, oth, x, ws.mstride, ws.gk, ws.gkstride, ub, np,
                                        p.ld, ws.mstride, C0, kb, rowsrc, copy, no_export, ws.tstride, next,
                                        next + kb_next, guard);
                 }
                 if ((e = hipEventRecord(ex.events[ev], ex.aux)) != hipSuccess) return e;
                 pending_b = true;
             } else {
+                launch_strip(stream, 0, np, 1, exn);
+                launch_transpose(stream);
                 ProfScope ps(prof, KC_UPDATE_OUT, stream);
                 hipLaunchKernelGGL((gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS, 128, (MI32_BW_PF != 0)>), dim3((np / 128) * (np / 128), batch),
                                    dim3(256), rank_bw2_lds_bytes<MI32_BW_BK>(kb), stream, cur, oth, x, ws.mstride, ws.gk,
-                                   ws.gkstride, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, exn, ws.tstride, 0, 0, guard);
+                                   ws.gkstride, ub, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, exn, ws.tstride, 0, 0, guard);
             }
             float *t = cur; cur = oth; oth = t;
         } else {

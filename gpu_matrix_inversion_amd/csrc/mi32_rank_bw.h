@@ -141,16 +141,16 @@ __device__ __forceinline__ void rank_bw2_tail(F &k_tile, int pf0)
 
 // One 128 x BN output tile (rt, ct) of matrix b (BN = 128 or 64: 4 waves as 2 x 2, 64 x BN/2 each).
 // rb_smem: rank_bw2_lds_bytes<BK, BN>(kdim) bytes of LDS.
-// PF: the old values C of the tile are fetched DURING the k-loop, one 32 x 32 sub-tile (16 loads per lane) per
-// k-tile over the last k-tiles but two, instead of after it: at the sizes where every workgroup of the chip reaches
-// its epilogue at the same moment the reads then travel while the matrix pipe works.  A wave's loads complete in
-// order, so the wait in front of a k-tile lets exactly the youngest chunk stay in flight (vmcnt(16)).
+// The accumulators START from the old values C (row-mapped), so that every element goes through one fmaf chain from
+// its old value, k ascending -- the reference's own operation order (mat_inv_32.cpp:28-38).  The old values are
+// requested before the first operand stage, so both travel together.  (PF is kept as a template parameter for the
+// call sites; round 2 fetched the old values under the last k-tiles, which the order from the old value rules out.)
 template <int BK, int BN = 128, bool PF = false>
 __device__ __forceinline__ void rank_bw2_tile(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
-    const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
-    const int *__restrict__ map_all, int copy_panel, const PanelExport &ex, size_t tstride, int skip_lo, int skip_hi,
-    int b, int rt, int ct, float *rb_smem)
+    const float *__restrict__ gk_all, size_t gkstride, const float *__restrict__ ub_all, int np, int ld, size_t mstride,
+    int c0, int kdim, const int *__restrict__ map_all, int copy_panel, const PanelExport &ex, size_t tstride, int skip_lo,
+    int skip_hi, int b, int rt, int ct, float *rb_smem)
 {
     constexpr int BM = 128;
     constexpr int TN = BN / 64;          // 32-column MFMA tiles per wave
@@ -161,7 +161,6 @@ __device__ __forceinline__ void rank_bw2_tile(
     float *s_a = rb_smem;                    // [2][BK][128]
     float *s_b = rb_smem + 2 * BK * 128;     // [2][BK][BN]
     int *s_map = reinterpret_cast<int *>(rb_smem + 2 * BK * (128 + BN));  // [128]  C rows of this tile
-    int *s_bmap = s_map + 128;               // [kdim] pivot rows of the block
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -171,10 +170,11 @@ __device__ __forceinline__ void rank_bw2_tile(
     const float *src = src_all + (size_t)b * mstride;
     float *dst = dst_all + (size_t)b * mstride;
     const float *gk = gk_all + (size_t)b * gkstride;
+    const float *ub = ub_all + (size_t)b * gkstride;
     const int *map = map_all + (size_t)b * np;
 
     if (col0 >= skip_lo && col0 < skip_hi) return;
-    if (col0 >= c0 && col0 + BN <= c0 + kdim) {  // tile inside the panel: those columns are G itself
+    if (col0 >= c0 && col0 + BN <= c0 + kdim) {  // tile inside the panel: those columns are up to date already
         if (copy_panel) {
             const float *g = g_all + (size_t)b * gstride;
             for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
@@ -185,17 +185,19 @@ __device__ __forceinline__ void rank_bw2_tile(
         }
         return;
     }
+    // Block bounds are multiples of 128, so a whole tile is either inside the block or outside it: the block's own
+    // pivot rows were finished by gj_block_strip_kernel
+    if (row0 >= c0 && row0 < c0 + kdim) return;
 
     MI32_RB_STAMP(0);
     if (tid < BM) s_map[tid] = map[row0 + tid];
-    for (int i = tid; i < kdim; i += 256) s_bmap[i] = map[c0 + i];
     __syncthreads();
 
     // per-lane source addresses of this wave's DMA slices: k-rows 2*(wave*ND + i) + (lane >> 5) of a stage
     const int lk = lane >> 5, lc4 = (lane & 31) * 4;
     const int lkb = lane / (BN / 4), lcb4 = (lane % (BN / 4)) * 4;  // B: k-row and column inside one LDS-DMA
-    const float *a_src = gk + (size_t)lk * np + row0 + lc4;  // + (kt + 2 * (wave * ND + i)) * np
-    const float *b_col = src + col0 + lcb4;                  // + s_bmap[kt + KPB * (wave * NDB + i) + lkb] * ld
+    const float *a_src = gk + (size_t)lk * np + row0 + lc4;   // + (kt + 2 * (wave * ND + i)) * np
+    const float *b_src = ub + (size_t)lkb * np + col0 + lcb4; // + (kt + KPB * (wave * NDB + i)) * np
 
 #define MI32_RB_ISSUE(STAGE, KT)                                                                       \
     _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                   \
@@ -204,59 +206,33 @@ __device__ __forceinline__ void rank_bw2_tile(
     }                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < NDB; ++i) {                                                  \
         const int kr = KPB * (wave * NDB + i);                                                         \
-        rb_glds16(b_col + (size_t)s_bmap[(KT) + kr + lkb] * ld, s_b + ((STAGE) * BK + kr) * BN);       \
+        rb_glds16(b_src + (size_t)((KT) + kr) * np, s_b + ((STAGE) * BK + kr) * BN);                   \
     }
-
-    rb_float16v acc[2][TN];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[tm][tn][reg] = 0.0f;
 
     const int lcol = lane & 31;
     const int lhalf = lane >> 5;
     const int nk = kdim / BK;
-    const bool tile_in_block = (row0 >= c0 && row0 < c0 + kdim);
-    constexpr int NCH = 2 * TN;                     // chunks of old values: one 32 x 32 sub-tile each
-    const bool pf = PF && nk >= NCH + 2;            // chunk c is issued in k-tile pf0 + c, the last one two k-tiles early
-    const int pf0 = nk - 2 - NCH;
-    float cv[2][TN][16];
+    rb_float16v acc[2][TN];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) cv[tm][tn][reg] = 0.0f;
-    MI32_RB_STAMP(1);
-    MI32_RB_ISSUE(0, 0)
-    // One k-tile.  WAIT16: the chunk of old values issued in the previous k-tile may stay in flight (everything older,
-    // this k-tile's operands included, has landed).  CH >= 0: this k-tile issues chunk CH, after its DMAs.
-    auto k_tile = [&](int t, auto WAIT16, auto CHUNK) {
-        constexpr bool wait16 = decltype(WAIT16)::value;
-        constexpr int ch = decltype(CHUNK)::value;
-        const int buf = t & 1;
-        // stage t has landed for this wave's DMAs; after the barrier for everyone's, and every wave is done
-        // reading the other buffer (k-tile t-1), which the next DMA overwrites
-        if (wait16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 1 < nk) { MI32_RB_ISSUE(buf ^ 1, (t + 1) * BK) }
-        if constexpr (ch >= 0) {
-            // the chunk must be YOUNGER than the DMAs above (the partial wait counts on it), and loads from a
-            // restrict-const pointer are invariant to the compiler -- it would hoist them over anything: their
-            // address goes through a register only this asm statement defines
-            int pin = 0;
-            asm volatile("" : "+v"(pin));
-            constexpr int tm = ch / TN, tn = ch % TN;
-            const int col = col0 + wc * (BN / 2) + tn * 32 + lcol + pin;
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = col0 + wc * (BN / 2) + tn * 32 + lcol;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                cv[tm][tn][reg] = src[(size_t)s_map[lr] * ld + col];
+                acc[tm][tn][reg] = src[(size_t)s_map[lr] * ld + col];
             }
         }
+    MI32_RB_STAMP(1);
+    MI32_RB_ISSUE(0, 0)
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        // stage t has landed for this wave's DMAs (and, the first time, the old values); after the barrier for
+        // everyone's, and every wave is done reading the other buffer (k-tile t-1), which the next DMA overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nk) { MI32_RB_ISSUE(buf ^ 1, (t + 1) * BK) }
         const float *pa = s_a + buf * BK * 128 + lhalf * 128 + wr * 64 + lcol;
         const float *pb = s_b + buf * BK * BN + lhalf * BN + wc * (BN / 2) + lcol;
         float af[2], bf[TN];
@@ -282,17 +258,6 @@ __device__ __forceinline__ void rank_bw2_tile(
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) bf[tn] = bfn[tn];
         }
-    };
-    typedef std::integral_constant<int, -1> NoChunk;
-    if (pf && !tile_in_block) {
-        // the last NCH + 2 k-tiles are peeled off the loop: straight-line code, where hipcc knows that nothing is
-        // pending on the registers a chunk is loaded into (inside a loop it waits for vmcnt(0) in front of each)
-        for (int t = 0; t < pf0; ++t) k_tile(t, std::false_type{}, NoChunk{});
-        if constexpr (PF) {
-            rank_bw2_tail<NCH>(k_tile, pf0);
-        }
-    } else {
-        for (int t = 0; t < nk; ++t) k_tile(t, std::false_type{}, NoChunk{});
     }
 #undef MI32_RB_ISSUE
     MI32_RB_STAMP(2);
@@ -302,27 +267,17 @@ __device__ __forceinline__ void rank_bw2_tile(
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int col = col0 + wc * (BN / 2) + tn * 32 + lcol;
-            // the old values C (row-mapped); the rows of the block itself start from 0.  Block bounds are
-            // multiples of 128, so a whole tile is either inside the block or outside it.
-            float(&cq)[16] = cv[tm][tn];
-            if (!tile_in_block && !pf) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                    cq[reg] = src[(size_t)s_map[lr] * ld + col];
-                }
-            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int grow = row0 + wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                cq[reg] += acc[tm][tn][reg];
-                dst[(size_t)grow * ld + col] = cq[reg];
+                dst[(size_t)grow * ld + col] = acc[tm][tn][reg];
             }
             // the next block's first sub-panels, compact and transposed: registers 4q .. 4q+3 are 4 consecutive rows
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                panel_export_store4(ex, tstride, b, np, col, row0 + wr * 64 + tm * 32 + 8 * q + 4 * lhalf, cq[4 * q],
-                                    cq[4 * q + 1], cq[4 * q + 2], cq[4 * q + 3]);
+                panel_export_store4(ex, tstride, b, np, col, row0 + wr * 64 + tm * 32 + 8 * q + 4 * lhalf,
+                                    acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2],
+                                    acc[tm][tn][4 * q + 3]);
         }
     MI32_RB_STAMP(3);
 #ifdef MI32_RB_STAMPS
@@ -338,16 +293,16 @@ __device__ __forceinline__ void rank_bw2_tile(
 template <int BK, int WPS, int BN = 128, bool PF = false>
 __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
-    const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
-    const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo, int skip_hi,
-    const int *__restrict__ guard)
+    const float *__restrict__ gk_all, size_t gkstride, const float *__restrict__ ub_all, int np, int ld, size_t mstride,
+    int c0, int kdim, const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo,
+    int skip_hi, const int *__restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) float rb_smem[];
     if (guard != nullptr && __builtin_amdgcn_readfirstlane(guard[blockIdx.y]) == MI32_RUNTIME_ERROR) return;  // given up
     int rt, ct;
     rb_tile_of(blockIdx.x, np / 128, np / BN, rt, ct);
-    rank_bw2_tile<BK, BN, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
-                              copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
+    rank_bw2_tile<BK, BN, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, ub_all, np, ld, mstride, c0, kdim,
+                              map_all, copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
 }
 
 // Persistent, residency-limited flavour for the look-ahead half (see blocked_invert): gridDim.x workgroups
@@ -358,9 +313,9 @@ __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
 template <int BK, bool PF = false>
 __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
-    const float *__restrict__ gk_all, size_t gkstride, int np, int ld, size_t mstride, int c0, int kdim,
-    const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo, int skip_hi,
-    const int *__restrict__ guard)
+    const float *__restrict__ gk_all, size_t gkstride, const float *__restrict__ ub_all, int np, int ld, size_t mstride,
+    int c0, int kdim, const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo,
+    int skip_hi, const int *__restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) float rb_smem[];
     if (guard != nullptr && __builtin_amdgcn_readfirstlane(guard[blockIdx.y]) == MI32_RUNTIME_ERROR) return;  // given up
@@ -368,8 +323,8 @@ __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
     for (int id = blockIdx.x; id < T * T; id += gridDim.x) {
         int rt, ct;
         rb_tile_of(id, T, T, rt, ct);
-        rank_bw2_tile<BK, 128, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, np, ld, mstride, c0, kdim, map_all,
-                                   copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
+        rank_bw2_tile<BK, 128, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, ub_all, np, ld, mstride, c0, kdim,
+                                   map_all, copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
         __syncthreads();  // the next tile re-uses the LDS buffers and maps
     }
 }

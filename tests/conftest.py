@@ -18,33 +18,40 @@ def pytest_configure(config):
 
 
 def golden_files():
-    """(input, float64 inverse) fixtures; the mirror_digest_* files are a different kind (see below)."""
+    """(input, float64 inverse) fixtures; the oracle_digest_* files are a different kind (see below)."""
     return sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-                  if not os.path.basename(p).startswith("mirror_digest_"))
+                  if not os.path.basename(p).startswith("oracle_digest_"))
 
 
-def load_mirror_digest(n):
-    """Digest of the oracle's blocked mirror on gate_matrix(n, seed), written by
-    tests/golden/make_mirror_digests.py in the build container: plan (widths, bw), sha256 of the
-    fp32 output bytes, 4096 sampled entries, per-row sums of |x|."""
-    d = np.load(os.path.join(GOLDEN, f"mirror_digest_N{n}.npz"), allow_pickle=False)
+def canonical_bytes(x):
+    """The fp32 bytes of a result with -0.0 stored as +0.0: a zero multiplier is skipped by the reference
+    (mat_inv_32.cpp:28) and multiplied through by the matrix cores, which can only differ in the sign of a zero."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    return (x + np.float32(0.0)).tobytes()
+
+
+def load_oracle_digest(n):
+    """Digest of the oracle's reference-order result on gate_matrix(n, seed), written by
+    tests/golden/make_oracle_digests.py in the build container: sha256 of the fp32 output bytes,
+    4096 sampled entries, per-row sums of |x|."""
+    d = np.load(os.path.join(GOLDEN, f"oracle_digest_N{n}.npz"), allow_pickle=False)
     return {k: d[k] for k in d.files}
 
 
-def check_against_mirror_digest(x, dig):
-    """Bit-exact comparison of a flat fp32 result with a mirror digest; on a mismatch the assertion
+def check_against_oracle_digest(x, dig):
+    """Bit-exact comparison of a flat fp32 result with an oracle digest; on a mismatch the assertion
     message says how many sampled entries differ and which rows' |x| sums are off."""
     import hashlib
 
     x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
     n = int(dig["n"])
     assert x.size == n * n
-    got = hashlib.sha256(x.tobytes()).digest()
+    got = hashlib.sha256(canonical_bytes(x)).digest()
     if got == bytes(dig["sha256"]):
         return
     bad = int((x[dig["idx"]] != dig["vals"]).sum())
     rows = np.nonzero(np.abs(x.reshape(n, n).astype(np.float64)).sum(axis=1) != dig["rowsum_abs"])[0]
-    raise AssertionError(f"N={n}: sha256 differs from the mirror's; {bad}/{dig['idx'].size} sampled entries differ, "
+    raise AssertionError(f"N={n}: sha256 differs from the oracle's; {bad}/{dig['idx'].size} sampled entries differ, "
                          f"{rows.size} rows differ (first {rows[:8].tolist()})")
 
 

@@ -107,8 +107,9 @@ def test_workspace_sizes():
     blocked = lib.mi32_workspace_bytes(n, 1, _lib.ALGO_BLOCKED)
     # two working copies of the N x N matrix (the reference holds two N x 2N panels + N x N)
     assert 2 * n * n * 4 <= sweep < 2 * n * n * 4 + (1 << 20)
-    # rows padded by 256 B, + five compact panels (32 x N) and eight maps, + the transposed block panel (256 x N)
-    assert 2 * n * n * 4 <= blocked < 2 * n * (n + 64) * 4 + 256 * n * 4 + (4 << 20)
+    # rows padded by 256 B, + five compact panels (32 x N), two multiplier panels (32 x 2N) and ten maps, + per block
+    # (256 pivots): the transposed multipliers, two pivot-row strips and two multiplier matrices (256 x N each)
+    assert 2 * n * n * 4 <= blocked < 2 * n * (n + 64) * 4 + 5 * 256 * n * 4 + (5 << 20)
     assert lib.mi32_workspace_bytes(0, 1, 0) == 0
     # padding to a multiple of 128 in the blocked path
     assert lib.mi32_workspace_bytes(1000, 1, _lib.ALGO_BLOCKED) >= 2 * 1024 * 1024 * 4

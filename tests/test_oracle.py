@@ -97,18 +97,45 @@ def test_fast_and_portable_oracle_builds_are_bit_identical(oracle):
                                                    ws.ctypes.data_as(ip), ws.size, bw, None) == 0
             outs.append(out)
         assert np.array_equal(outs[0], outs[1]), (n, bw, w)
+        # ... and the blocked evaluation of the sequential arithmetic (AVX2 fnmadd lanes vs fmaf through libm)
+        outs = []
+        for lib in libs:
+            lib.gjo_matrix_inv_32_blocked_exact.restype = ctypes.c_int
+            lib.gjo_matrix_inv_32_blocked_exact.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp, ctypes.c_int, ip]
+            out = np.empty(n * n, np.float32)
+            assert lib.gjo_matrix_inv_32_blocked_exact(a.ctypes.data_as(fp), a.size, n, out.ctypes.data_as(fp), 128, None) == 0
+            outs.append(out)
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), n
 
 
-def test_mirror_digest_4096_reproduced_here(oracle):
-    """The committed digest of the blocked mirror at N = 4096 (tests/golden/make_mirror_digests.py) is
-    reproduced by whatever oracle build runs on this machine: the mirror the GPU tests compare with is
-    the same function of its input everywhere."""
-    from conftest import check_against_mirror_digest, load_mirror_digest
+def test_oracle_digest_4096_reproduced_here(oracle):
+    """The committed digest of the reference-order result at N = 4096 (tests/golden/make_oracle_digests.py) is
+    reproduced by whatever oracle build runs on this machine: what the GPU tests compare with is the same
+    function of its input everywhere."""
+    from conftest import check_against_oracle_digest, load_oracle_digest
 
-    dig = load_mirror_digest(4096)
+    dig = load_oracle_digest(4096)
     a = gate_matrix(4096, int(dig["seed"]))
-    x = oracle.matrix_inv_32_blocked2(a, 4096, dig["widths"].tolist(), int(dig["bw"]))
-    check_against_mirror_digest(x, dig)
+    x = oracle.matrix_inv_32_blocked_exact(a, 4096, 64)   # another block width than the generator's: same bits
+    check_against_oracle_digest(x, dig)
+
+
+def test_round2_delayed_update_order_was_less_accurate_on_the_references_inputs(oracle):
+    """Why the blocked HIP path changed its operation order in round 3.  Rounds 1-2 applied a block of pivots to the
+    other columns through the block's COMPOSITE transformation (gjo_matrix_inv_32_blocked2: the transformed panel
+    times the pivot rows as they stood before the block).  On the reference's own ill-conditioned inputs (U(0,100),
+    matrix_inv_pyopencl.py:17; rand, test_inversa_mat.mlx) that is ~2x less accurate than the reference's own
+    order -- one fmaf per element and pivot step (mat_inv_32.cpp:28-38) -- which the blocked evaluation
+    gjo_matrix_inv_32_blocked_exact reproduces bit for bit."""
+    n = 1024
+    for kind, hi in (("ref100", 100.0), ("rand", 1.0)):
+        a = np.random.default_rng(4242).uniform(0, hi, (n, n)).astype(np.float32)
+        seq = oracle.matrix_inv_32_inplace(a, n)
+        exact = oracle.matrix_inv_32_blocked_exact(a, n, 256)
+        composite = oracle.matrix_inv_32_blocked2(a, n, 16, 256)
+        r_seq, r_comp = oracle.residual_inf(a, seq, n), oracle.residual_inf(a, composite, n)
+        assert np.array_equal(seq.view(np.uint32), exact.view(np.uint32))
+        assert r_comp > 1.5 * r_seq, (kind, r_seq, r_comp)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 16, 33, 64, 100, 130, 257])
