@@ -151,11 +151,16 @@ def oracle_port_baseline(n_small=1024):
 
 
 def reference_distribution_residuals(inv, n, torch, dev, budget_s=25.0):
-    """||A X - I||_inf on the reference's own input distributions (ungated: fp32 Gauss-Jordan cannot reach 1e-3
-    there), ours next to NumPy's on the same matrix.  matrix_inv_pyopencl.py:17, matrix_inv_numpy.py:40
-    (U(0,100)) and the MATLAB live script's rand(N,N) (U(0,1))."""
+    """||A X - I||_inf on the reference's own input distributions (ungated at 1e-3: fp32 Gauss-Jordan cannot reach it
+    there; gated in the tests relative to the reference-order elimination), ours next to the CPU oracle's
+    (the reference's operation order, step by step) and NumPy's on the same matrix.  matrix_inv_pyopencl.py:17,
+    matrix_inv_numpy.py:40 (U(0,100)) and the MATLAB live script's rand(N,N) (U(0,1))."""
     out = {}
     t_start = time.perf_counter()
+    try:
+        import oracle as O
+    except Exception:  # the oracle is optional for the bench
+        O = None
     for name, hi in (("D_ref100", 100.0), ("D_rand", 1.0)):
         a = np.random.default_rng(4242).uniform(0.0, hi, (n, n)).astype(np.float32)
         ta = torch.from_numpy(a).to(dev)
@@ -164,6 +169,14 @@ def reference_distribution_residuals(inv, n, torch, dev, budget_s=25.0):
         torch.cuda.synchronize()
         entry = {"ours_residual_inf": float(r[0, 0]), "ours_residual_inf_left": float(r[0, 1]),
                  "ours_frobenius_metric": float(r[0, 2]), "status": int(st[0])}
+        if O is not None and n <= 4096:
+            # the reference-order elimination (gjo_matrix_inv_32_inplace's bits through its cache-blocked evaluation)
+            xo = O.matrix_inv_32_blocked_exact(a, n, 128)
+            ro = inv.residual(ta, torch.from_numpy(xo.reshape(n, n)).to(dev))
+            torch.cuda.synchronize()
+            entry["reference_order_gj_residual_inf"] = float(ro[0, 0])
+            entry["reference_order_gj_residual_inf_left"] = float(ro[0, 1])
+            entry["ours_equals_reference_order_gj_bit_for_bit"] = bool(np.array_equal(x.cpu().numpy().reshape(-1), xo))
         if time.perf_counter() - t_start < budget_s:
             xn = np.linalg.inv(a)
             rn = inv.residual(ta, torch.from_numpy(np.ascontiguousarray(xn, dtype=np.float32)).to(dev))
@@ -201,6 +214,8 @@ def main():
     ap.add_argument("--block-width", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the host-pointer leg (matrix_inv_32(vec, N)): profiler passes only want the timed loop")
     ap.add_argument("--distribute", dest="distribute", action="store_true", default=True,
                     help="N > 1 (default on): also time the batch scattered from / gathered to rank 0 over RCCL (xGMI)")
     ap.add_argument("--no-distribute", dest="distribute", action="store_false")
@@ -360,7 +375,7 @@ def main():
 
     # T_e2e through the host-pointer drop-in (rank 0 only; pageable host memory both ways)
     e2e = None
-    if rank == 0:
+    if rank == 0 and not args.no_e2e:
         reps = 5 if n <= 4096 else 2
         times, computes = [], []
         flat = host.reshape(batch, -1)

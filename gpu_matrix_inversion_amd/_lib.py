@@ -24,8 +24,7 @@ ALGO_AUTO = 0
 ALGO_SWEEP = 1
 ALGO_BLOCKED = 2
 ALGO_NAMES = {"auto": ALGO_AUTO, "sweep": ALGO_SWEEP, "blocked": ALGO_BLOCKED}
-KERNEL_CLASSES = ("init", "sweep_step", "panel", "update_in_block", "update_rank_bw", "finish", "panel_transpose",
-                  "pivot_row_strip")
+KERNEL_CLASSES = ("init", "sweep_step", "panel", "update_in_block", "update_rank_bw", "finish", "panel_transpose")
 
 # every symbol include/mat_inv_32_c.h declares
 C_ABI_SYMBOLS = (

@@ -51,6 +51,7 @@
 // checks: inv(diag(A, I)) = diag(inv(A), I); a real column only ever takes its
 // pivot from the real rows, so the padding is never swapped into the matrix.
 #include <cstdlib>
+#include <mutex>
 #include <utility>
 
 #include "mi32_internal.h"
@@ -163,6 +164,9 @@ struct BlockedWs {
     float *mf[2];       // the block's NEGATED multipliers, np x bw row-major BY BLOCK-START ROW INDEX (never permuted);
                         // double-buffered across blocks (the look-ahead half reads block b's while block b+1 runs)
     float *ub[2];       // the block's pivot rows as their own steps saw them (U), bw x np: B operand of the rank-bw update
+    float *xs[2];       // the block's pivot rows after their own sub-panel's last step, bw x np: where their
+                        // accumulation starts in the rank-bw update
+    float *xst;         // gj_block_strip_kernel: the pivot rows of the groups a call leaves to the next one
     float *gk;          // the block's multipliers transposed and in final row order, bw x np: its A operand
     size_t gkstride;    // floats per matrix in gk / ub
     size_t mfstride;    // floats per matrix in mf
@@ -222,7 +226,11 @@ static size_t blocked_carve(const BlockedPlan &p, int batch, void *base, Blocked
     for (int i = 0; i < 2; ++i) {
         if (o) o->ub[i] = (float *)(c + off);
         off += gkbytes * batch;
+        if (o) o->xs[i] = (float *)(c + off);
+        off += gkbytes * batch;
     }
+    if (o) o->xst = (float *)(c + off);
+    off += gkbytes * batch;
     const size_t mfbytes = align256((size_t)p.np * p.bw * sizeof(float));
     if (o) o->mfstride = mfbytes / sizeof(float);
     for (int i = 0; i < 2; ++i) {
@@ -334,28 +342,65 @@ __device__ __forceinline__ float lane_bcast(float v, int srclane)
 // The multipliers of a step do not depend on the chain: they are read from LDS kStripAhead steps early into a
 // rotating window of registers, and scheduling barriers keep hipcc from sinking the reads back down to their uses
 // (left alone it puts two dependent LDS round trips, ~250 cycles, into each of the BK dependent steps).
+//
+// The division x / pivot (fixRow, mat_inv_32.cpp:149: IEEE, correctly rounded) is the other half of a step's
+// latency: hipcc expands it into v_div_scale x2, v_rcp, 6 fma, v_div_fmas, v_div_fixup -- 11 dependent instructions
+// of which only five depend on x once the operands need no scaling.  strip_div splits it: the pivot's part
+// (reciprocal and its Newton step: the very instructions of the expansion, on the unscaled pivot) is computed with
+// the prefetch, kStripAhead steps early; the chain keeps q0 = x r1, e1 = fma(-d, q0, x), q1 = fma(e1, r1, q0),
+// e2 = fma(-d, q1, x), q = fma(e2, r1, q1).  v_div_scale leaves both operands alone and v_div_fixup returns q as it is
+// exactly when (ISA, V_DIV_SCALE_F32 / V_DIV_FIXUP_F32) neither is zero, denormal, infinite or NaN, the exponents are
+// less than 96 apart, the numerator's biased exponent is above 23 and the denominator's below 253: the fast path is
+// taken for 2^-47 <= |.| < 2^48 on both sides -- bit for bit the full expansion's result -- and for an exact zero
+// numerator; anything else takes the expansion itself (one wave-uniform branch).
 static constexpr int kStripAhead = 3;
+__device__ __forceinline__ bool strip_div_in_range(float v)
+{
+    return __builtin_fabsf(v) >= 0x1p-47f && __builtin_fabsf(v) < 0x1p48f;
+}
+// x / d, d = -dneg; r1 = the refined reciprocal of d (strip_fetch); d_ok: d is in the fast path's range.
+// An exact zero x takes the fast path too: its five instructions return a zero (of either sign: -0.0 == 0.0, and
+// nothing downstream can tell them apart but the sign of another zero).
+__device__ __forceinline__ float strip_div(float x, float dneg, float r1, bool d_ok)
+{
+    float q = x * r1;
+    float e = __builtin_fmaf(dneg, q, x);
+    q = __builtin_fmaf(e, r1, q);
+    e = __builtin_fmaf(dneg, q, x);
+    q = __builtin_fmaf(e, r1, q);
+    const bool fast = d_ok && (strip_div_in_range(x) || x == 0.0f);
+    if (!__all(fast)) {
+        const float full = x / -dneg;
+        q = fast ? q : full;
+    }
+    return q;
+}
 template <int BK, int M>
 __device__ __forceinline__ void strip_fetch(float (&nfw)[kStripAhead + 1][BK / 4], float (&pw)[kStripAhead + 1],
-                                            const float *s_lt, int LT, int g)
+                                            float (&rw)[kStripAhead + 1], const float *s_lt, int LT, int g)
 {
     constexpr int CPT = BK / 4;
     if constexpr (M < BK) {
 #pragma unroll
         for (int j = 0; j < CPT; ++j) nfw[M % (kStripAhead + 1)][j] = s_lt[M * LT + CPT * g + j];
-        pw[M % (kStripAhead + 1)] = s_lt[M * LT + M];
+        const float dneg = s_lt[M * LT + M];  // -pivot
+        const float r = __builtin_amdgcn_rcpf(-dneg);
+        const float e0 = __builtin_fmaf(dneg, r, 1.0f);
+        pw[M % (kStripAhead + 1)] = dneg;
+        rw[M % (kStripAhead + 1)] = __builtin_fmaf(e0, r, r);
     }
 }
 template <int BK, int M>
 __device__ __forceinline__ void strip_step(float (&x)[BK / 4], float (&uu)[BK], float (&nfw)[kStripAhead + 1][BK / 4],
-                                           float (&pw)[kStripAhead + 1], const float *s_lt, int LT, int g)
+                                           float (&pw)[kStripAhead + 1], float (&rw)[kStripAhead + 1], const float *s_lt,
+                                           int LT, int g, bool d_ok)
 {
     constexpr int CPT = BK / 4;
     constexpr int kQuad = (M / CPT) * 0x55;  // quad_perm:[q,q,q,q]
-    strip_fetch<BK, M + kStripAhead>(nfw, pw, s_lt, LT, g);
+    strip_fetch<BK, M + kStripAhead>(nfw, pw, rw, s_lt, LT, g);
     __builtin_amdgcn_sched_barrier(0);
     const float xm = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[M % CPT]), kQuad, 0xf, 0xf, false));
-    const float u = xm / -pw[M % (kStripAhead + 1)];
+    const float u = strip_div(xm, pw[M % (kStripAhead + 1)], rw[M % (kStripAhead + 1)], d_ok);
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const float upd = __builtin_fmaf(nfw[M % (kStripAhead + 1)][j], u, x[j]);
@@ -370,12 +415,15 @@ __device__ __forceinline__ void strip_steps(float (&x)[BK / 4], const float *s_l
                                             std::integer_sequence<int, Ms...>)
 {
     float uu[BK];
-    float nfw[kStripAhead + 1][BK / 4], pw[kStripAhead + 1];
-    strip_fetch<BK, 0>(nfw, pw, s_lt, LT, g);
-    strip_fetch<BK, 1>(nfw, pw, s_lt, LT, g);
-    strip_fetch<BK, 2>(nfw, pw, s_lt, LT, g);
+    float nfw[kStripAhead + 1][BK / 4], pw[kStripAhead + 1], rw[kStripAhead + 1];
+    // all BK pivots inside the fast division's range?  (one LDS read per lane and a ballot, before the chain starts)
+    const int lane_m = (int)(threadIdx.x & 63) % BK;
+    const bool d_ok = __all(strip_div_in_range(s_lt[lane_m * LT + lane_m]));
+    strip_fetch<BK, 0>(nfw, pw, rw, s_lt, LT, g);
+    strip_fetch<BK, 1>(nfw, pw, rw, s_lt, LT, g);
+    strip_fetch<BK, 2>(nfw, pw, rw, s_lt, LT, g);
     static_assert(kStripAhead == 3, "the three fetches above");
-    (strip_step<BK, Ms>(x, uu, nfw, pw, s_lt, LT, g), ...);
+    (strip_step<BK, Ms>(x, uu, nfw, pw, rw, s_lt, LT, g, d_ok), ...);
     if (g == 0) {
 #pragma unroll
         for (int m = 0; m < BK; ++m) s_u[m * LDU] = uu[m];
@@ -450,6 +498,9 @@ struct PanelGroup {
 template <int V, typename T>
 __device__ __forceinline__ void mt_store(float *sbase, unsigned voff, T v)
 {
+#ifdef MI32_TIMING_NO_MT_STORE  // timing-only builds (wrong results): what do the multiplier stores cost the panel?
+    return;
+#endif
     if constexpr (V == 1) asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase));
     else if constexpr (V == 2) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase));
     else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase));
@@ -496,7 +547,7 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
             mvecV v;
 #pragma unroll
             for (int j = 0; j < V; ++j) v[j] = col[g * V + j];
-            if constexpr (V == 1) mt_store<1>(mtp + (size_t)R * mtld + g * (V * NT), voff, col[g]);
+            if constexpr (V == 1) mt_store<1>(mtp + (size_t)R * mtld + g * (V * NT), voff, v[0]);
             else mt_store<V>(mtp + (size_t)R * mtld + g * (V * NT), voff, v);
         }
     }
@@ -738,6 +789,14 @@ struct SubpanelArgs {
     const float *u_pt_in;  // Pt_t (for the rows above the block)
     const float *u_aux;    // aux_t
     PanelExport u_exp;     // the columns of sub-panel t+2 -> its compact panel input
+    int upd_wgs;           // workgroups of the launch that run update tiles
+    // ---- strip(t) of the columns outside the block (absent when os_on == 0): uses the u_ fields of sub-panel t
+    int os_on;
+    int os_first, os_ntiles;  // the tiles' columns: os_ntiles x 64 from os_first on (os_first == 0: the block's own are skipped)
+    const float *os_cur;   // the working copy the columns outside the block are still valid in
+    float *os_ub, *os_xs;  // the block's u rows / its pivot rows after their own sub-panel, kb x np each
+    size_t ubstride;
+    int drop_groups;       // tests only: panel workgroups left out of a multi-workgroup panel launch
 };
 
 template <int NW, int W>
@@ -1232,121 +1291,270 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
     }
 }
 
-// ---- one launch per sub-panel: panel(s) || update(s-1) ------------------------------
+// ---- strip(t): what the columns OUTSIDE the block see of sub-panel t's W pivot steps ---------------
+// One 256-thread group per 64-column tile outside the block.  The W pivot rows of t have not been touched by the
+// block's earlier sub-panels in these columns (their update is delayed to the end of the block), so their values at
+// the start of the block first take the block's earlier steps,
+//     x[kk][j] = fmaf(-f_m[row kk], u_m[j], x[kk][j]),  m = 0 .. c0 - C0 - 1 ascending        (mat_inv_32.cpp:28-38)
+// (u_m: left in ub by the strips of the earlier sub-panels; -f_m: the block's multiplier matrix mf), then run their
+// own W steps (strip_step: W dependent IEEE divisions).  Out: ub[c0 - C0 + m][j] = u_m[j], the pivot row of step m
+// as fixColumn sees it = the B operand of the block's rank-bw update, and xs[c0 - C0 + kk][j] = pivot row kk after
+// the sub-panel's last step = where that row's accumulation starts in the rank-bw update (which applies the later
+// sub-panels' steps to it and nothing else: gj_mult_transpose_kernel masks the rest).
+// The tiles ride in the launch of the NEXT panel (or in the block's last in-block update): off the chain of pivot steps.
+template <int BK>
+struct __attribute__((aligned(16))) OStripShared {
+    static constexpr int MC = 32;       // earlier steps per round of loads
+    static constexpr int LDU = 64 + 4;
+    static constexpr int LT = BK + 4;
+    float s_ub[MC * LDU];   // u_m of a round x 64 columns
+    float s_mf[MC * LT];    // -f_m of the W pivot rows in a round, [m][row]
+    float s_x[BK * LDU];    // the W pivot rows x 64 columns at the start of the block; after the strip: u_m
+    float s_xs[BK * LDU];   // the W pivot rows after the sub-panel's last step
+    float s_lt[BK * LT];    // -multipliers of the W pivot rows in the W steps of t, [step][row]
+    int s_q[BK], s_idx[BK]; // their row index at the start of the block / in the order before t's swaps
+};
+
+template <int BK>
+__device__ __forceinline__ void ostrip_body(const SubpanelArgs &A, int tile, unsigned char *smem_group, int tid)
+{
+    typedef OStripShared<BK> S;
+    constexpr int MC = S::MC, LDU = S::LDU, LT = S::LT, CPT = BK / 4;
+    S &T = *reinterpret_cast<S *>(smem_group);
+    const int np = A.np, ld = A.ld, c0 = A.u_c0, C0 = A.C0, kb = A.kb;
+    const int tiles = A.os_ntiles;
+    // The 256-thread groups of a wider workgroup run different tiles and share the workgroup's barriers: no group
+    // leaves early.  A group past the last tile repeats the last one without storing; a given-up matrix (its row
+    // maps still hold valid positions) is computed and not stored.
+    bool store_ok = tile < tiles * A.batch;
+    if (!store_ok) tile = tiles * A.batch - 1;
+    const int b = tile / tiles;
+    store_ok = store_ok && !matrix_given_up(A.guard, b);
+    int col0 = A.os_first + (tile % tiles) * 64;
+    if (A.os_first == 0 && col0 >= C0) col0 += kb;  // all columns but the block's own
+    const float *cur = A.os_cur + (size_t)b * A.mstride;
+    const float *mt = A.u_mt + (size_t)b * A.mtstride;
+    const float *mf = A.u_mf + (size_t)b * A.mfstride;
+    float *ub = A.os_ub + (size_t)b * A.ubstride;
+    float *xs = A.os_xs + (size_t)b * A.ubstride;
+    const int K = c0 - C0;  // the block's steps before this sub-panel
+    // (every group executes the same number of barriers: K is the same for all of them)
+    if (tid < BK) {
+        T.s_idx[tid] = (A.u_submap + (size_t)b * np)[c0 + tid];
+        T.s_q[tid] = (A.u_rowsrc + (size_t)b * np)[c0 + tid];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < (BK * 16 + 255) / 256; ++q) {
+        const int idx = tid + q * 256;
+        if (idx < BK * 16)
+            *reinterpret_cast<float4 *>(&T.s_x[(idx / 16) * LDU + (idx % 16) * 4]) =
+                *reinterpret_cast<const float4 *>(cur + (size_t)T.s_q[idx / 16] * ld + col0 + (idx % 16) * 4);
+    }
+    for (int i = tid; i < BK * BK; i += 256)
+        T.s_lt[(i % BK) * LT + i / BK] = -mt[(size_t)(i % BK) * A.mtld + T.s_idx[i / BK]];
+    __syncthreads();
+    const int c = tid >> 2, g = tid & 3;
+    float x[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) x[j] = T.s_x[(CPT * g + j) * LDU + c];
+    for (int m0 = 0; m0 < K; m0 += MC) {
+        const int mc = (K - m0 < MC) ? (K - m0) : MC;  // a multiple of BK
+#pragma unroll
+        for (int q = 0; q < MC * 16 / 256; ++q) {
+            const int idx = tid + q * 256;
+            if (idx < mc * 16)
+                *reinterpret_cast<float4 *>(&T.s_ub[(idx / 16) * LDU + (idx % 16) * 4]) =
+                    *reinterpret_cast<const float4 *>(ub + (size_t)(m0 + idx / 16) * np + col0 + (idx % 16) * 4);
+        }
+        for (int idx = tid; idx < BK * (mc / 4); idx += 256) {
+            const int kk = idx / (mc / 4), m4 = (idx % (mc / 4)) * 4;
+            const float4 v = *reinterpret_cast<const float4 *>(mf + (size_t)T.s_q[kk] * A.mf_ld + m0 + m4);
+            T.s_mf[(m4 + 0) * LT + kk] = v.x;
+            T.s_mf[(m4 + 1) * LT + kk] = v.y;
+            T.s_mf[(m4 + 2) * LT + kk] = v.z;
+            T.s_mf[(m4 + 3) * LT + kk] = v.w;
+        }
+        __syncthreads();
+        for (int mm = 0; mm < mc; mm += BK) {
+#pragma unroll
+            for (int i = 0; i < BK; ++i) {
+                const float u = T.s_ub[(mm + i) * LDU + c];
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) x[j] = __builtin_fmaf(T.s_mf[(mm + i) * LT + CPT * g + j], u, x[j]);
+            }
+        }
+        __syncthreads();
+    }
+    strip_steps<BK>(x, T.s_lt, LT, g, &T.s_x[c], LDU, std::make_integer_sequence<int, BK>{});
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) T.s_xs[(CPT * g + j) * LDU + c] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < (BK * 16 + 255) / 256; ++q) {
+        const int idx = tid + q * 256;
+        if (idx < BK * 16 && store_ok) {
+            const int kk = idx / 16, c4 = (idx % 16) * 4;
+            *reinterpret_cast<float4 *>(ub + (size_t)(K + kk) * np + col0 + c4) =
+                *reinterpret_cast<const float4 *>(&T.s_x[kk * LDU + c4]);
+            *reinterpret_cast<float4 *>(xs + (size_t)(K + kk) * np + col0 + c4) =
+                *reinterpret_cast<const float4 *>(&T.s_xs[kk * LDU + c4]);
+        }
+    }
+}
+
+// ---- one launch per sub-panel: panel(s) || update(s-1) || strip(s-1) ------------------------------
 template <int NT, int RPT, int W, bool FUSED>
 constexpr size_t subpanel_lds_bytes()
 {
     const size_t pb = panel_shared_bytes<NT / 64, W>() + (size_t)2 * RPT * NT * sizeof(int);
     const size_t ub = FUSED ? sizeof(UpdateTileShared<W>) * (NT / 256) : 0;
-    return pb > ub ? pb : ub;
+    const size_t ob = sizeof(OStripShared<W>) * (NT / 256);
+    const size_t m = pb > ub ? pb : ub;
+    return m > ob ? m : ob;
 }
 
-// FUSED: workgroups [0, batch) are the panels of sub-panel s, the others the update tiles of sub-panel s-1
-// (NT / 256 tiles each).  !FUSED: the panel alone.
+// Workgroups [0, batch) (where panel_on) are the panels of sub-panel s; FUSED: the next A.upd_wgs are the update
+// tiles of sub-panel s-1 (NT / 256 tiles each); the rest are strip tiles of sub-panel s-1 (NT / 256 each).
 template <int NT, int RPT, int W, bool FUSED>
 __global__ __launch_bounds__(NT) void gj_subpanel_kernel(SubpanelArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
-    if constexpr (FUSED) {
-        const int npanel = A.panel_on ? A.batch : 0;
-        if ((int)blockIdx.x < npanel) panel_body<NT, RPT, W, true, false>(A, (int)blockIdx.x, 0, sp_smem);
-        else inblock_update_body<W, NT / 256>(A, (int)blockIdx.x - npanel, sp_smem);
-    } else {
-        panel_body<NT, RPT, W, false, false>(A, (int)blockIdx.x, 0, sp_smem);
+    const int npanel = A.panel_on ? A.batch : 0;
+    int u = (int)blockIdx.x;
+    if (u < npanel) {
+        panel_body<NT, RPT, W, FUSED, false>(A, u, 0, sp_smem);
+        return;
     }
+    u -= npanel;
+    if constexpr (FUSED) {
+        if (u < A.upd_wgs) {
+            inblock_update_body<W, NT / 256>(A, u, sp_smem);
+            return;
+        }
+        u -= A.upd_wgs;
+    }
+    const int grp = threadIdx.x >> 8;
+    ostrip_body<W>(A, u * (NT / 256) + grp, sp_smem + (size_t)grp * sizeof(OStripShared<W>), threadIdx.x & 255);
 }
 
 // A panel of more than kPanelGroupRows rows: A.ngroups workgroups per matrix (all must be resident at once:
-// the host only uses this for small batches), kPanelGroupRows rows each.
+// the host only uses this for small batches), kPanelGroupRows rows each; then the strip tiles of the sub-panel before.
 template <int W>
 __global__ __launch_bounds__(1024) void gj_panel_multi_kernel(SubpanelArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     static_assert(1024 * 4 == kPanelGroupRows, "1024 threads x 4 rows per lane");
-    panel_body<1024, 4, W, false, true>(A, (int)blockIdx.x / A.ngroups, (int)blockIdx.x % A.ngroups, sp_smem);
+    const int npanel = A.batch * A.ngroups - A.drop_groups;
+    if ((int)blockIdx.x < npanel) {
+        panel_body<1024, 4, W, false, true>(A, (int)blockIdx.x / A.ngroups, (int)blockIdx.x % A.ngroups, sp_smem);
+        return;
+    }
+    const int grp = threadIdx.x >> 8;
+    ostrip_body<W>(A, ((int)blockIdx.x - npanel) * 4 + grp, sp_smem + (size_t)grp * sizeof(OStripShared<W>),
+                   threadIdx.x & 255);
 }
 
-// update(t) alone: one 64 x 64 tile per 256-thread workgroup
+// update(t) alone: one 64 x 64 tile per 256-thread workgroup; then (the block's last sub-panel) its strip tiles
 template <int W>
 __global__ __launch_bounds__(256) void gj_inblock_update_kernel(SubpanelArgs A)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char upd_smem[sizeof(UpdateTileShared<W>)];
-    inblock_update_body<W, 1>(A, (int)blockIdx.x, upd_smem);
+    constexpr size_t kBytes = sizeof(UpdateTileShared<W>) > sizeof(OStripShared<W>) ? sizeof(UpdateTileShared<W>)
+                                                                                    : sizeof(OStripShared<W>);
+    __shared__ __attribute__((aligned(16))) unsigned char upd_smem[kBytes];
+    if ((int)blockIdx.x < A.upd_wgs) inblock_update_body<W, 1>(A, (int)blockIdx.x, upd_smem);
+    else ostrip_body<W>(A, (int)blockIdx.x - A.upd_wgs, upd_smem, threadIdx.x);
 }
 
-// ---- the block's pivot-row strip: what every column outside the block sees of its kb pivot steps -----
-// One workgroup per CT-column tile outside the block keeps the kb pivot rows x CT columns in LDS and runs the
-// block's kb pivot steps on them, 16 at a time: strip_step on the 16 pivot rows of the group (u_m, 16 dependent
-// IEEE divisions), then every other pivot row takes its 16 fmaf (one v_mfma_f32_32x32x2_f32 chain with the old
-// value as C operand, k ascending).  Out: ub[m][j] = u_m[j] -- the pivot row of step m as fixColumn saw it
-// (mat_inv_32.cpp:28-38), the B operand of the rank-bw update -- and the kb pivot rows after the block's last
-// step, written to rows [C0, C0 + kb) of the new working copy (and to the next block's compact panel inputs).
-// mf[q][m] = -f_m of the row whose index at the start of the block was q (own step: -pivot); map = rowsrc.
-template <int CT>
+// ---- the block's pivot-row strips in ONE launch, for the columns strip(t) could not follow -----
+// With the look-ahead, the columns outside the block are still being written by the previous block's second-stream
+// update while this block's panels run: their strips can only start when that is done.  One workgroup per CT-column
+// tile keeps the kb pivot rows x CT columns in the accumulator registers of its 16 waves (one 32 x 32 tile each) and
+// runs the block's pivot steps on them, G (= the block's sub-panel width) at a time: the G rows of a group go
+// through LDS and strip_step (u_m; G dependent IEEE divisions), then every LATER pivot row takes its G fmaf (one
+// v_mfma_f32_32x32x2_f32 chain with the old value as C operand, k ascending).  Out, exactly what the strip(t) tiles
+// leave: ub[m][j] = u_m[j], and xs[k][j] = pivot row k after its own sub-panel's last step.
+// The groups [g_lo, g_hi) of one call: a block's strips can start before its last panels have run -- the rows of the
+// groups still to come are parked in xst in between.  mf[q][m] = -f_m of the row whose index at the start of the
+// block was q (own step: -pivot); map = rowsrc.
+template <int CT, int G>
 constexpr size_t block_strip_lds_bytes(int kb)
 {
-    return ((size_t)kb * (CT + 4) + (size_t)16 * (kb + 4) + (size_t)2 * 16 * (CT + 4)) * sizeof(float) + (size_t)kb * sizeof(int);
+    return ((size_t)G * (CT + 4) + (size_t)G * (kb + 4) + (size_t)2 * G * (CT + 4)) * sizeof(float) + (size_t)kb * sizeof(int);
 }
 static constexpr int kStripThreads = 1024;  // 16 waves: one 32 x 32 tile of the pivot rows each (kb 256, CT 64)
-template <int CT>
-__global__ __launch_bounds__(kStripThreads) void gj_block_strip_kernel(const float *__restrict__ src_all, float *__restrict__ dst_all,
-                                                              size_t mstride, int np, int ld,
+static constexpr int kStripTPW = 1;         // tiles per wave: kb <= 256 runs CT = 64 (<= 16 tiles), wider blocks CT = 32 (<= 16 tiles)
+template <int CT, int G>
+__global__ __launch_bounds__(kStripThreads) void gj_block_strip_kernel(const float *__restrict__ src_all, size_t mstride, int np, int ld,
                                                               const float *__restrict__ mf_all, size_t mfstride, int mf_ld,
-                                                              float *__restrict__ ub_all, size_t ubstride, int C0, int kb,
+                                                              float *__restrict__ ub_all, float *__restrict__ xs_all,
+                                                              float *__restrict__ xst_all, size_t ubstride, int C0, int kb,
                                                               const int *__restrict__ map_all, int col_lo, int col_hi,
-                                                              int inside, PanelExport ex, size_t tstride,
+                                                              int inside, int g_lo, int g_hi,
                                                               const int *__restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) float bs_smem[];
     constexpr int LDX = CT + 4;
     constexpr int NT = kStripThreads;
+    constexpr int CTT = CT / 32;  // tiles per row of tiles
     const int LT = kb + 4;
-    float *s_x = bs_smem;                  // [kb][LDX]  the pivot rows
-    float *s_lt = s_x + (size_t)kb * LDX;  // [16][LT]   -f of the current 16 steps, [step][pivot row]
-    float *s_u = s_lt + 16 * LT;           // [2][16][LDX]  u_m of the current 16 steps (and of the previous 16)
-    int *s_q = reinterpret_cast<int *>(s_u + 2 * 16 * LDX);  // [kb] block-start row index of every pivot row
+    float *s_x = bs_smem;                  // [G][LDX]   the rows of the current group
+    float *s_lt = s_x + G * LDX;           // [G][LT]    -f of the current G steps, [step][pivot row]
+    float *s_u = s_lt + G * LT;            // [2][G][LDX]  u_m of the current G steps (and of the previous G)
+    int *s_q = reinterpret_cast<int *>(s_u + 2 * G * LDX);  // [kb] block-start row index of every pivot row
 
     const int b = blockIdx.y;
     if (matrix_given_up(guard, b)) return;
     const int col0 = blockIdx.x * CT;
     if (col0 >= C0 && col0 < C0 + kb) return;  // the block's own columns are up to date already
-    const bool in_range = (col0 >= col_lo && col0 < col_hi);
-    if (in_range != (inside != 0)) return;     // the look-ahead splits the columns between two launches
+    if ((col0 >= col_lo && col0 < col_hi) != (inside != 0)) return;  // the look-ahead splits the columns between two launches
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const float *src = src_all + (size_t)b * mstride;
-    float *dst = dst_all + (size_t)b * mstride;
     const float *mf = mf_all + (size_t)b * mfstride;
     float *ub = ub_all + (size_t)b * ubstride;
+    float *xs = xs_all + (size_t)b * ubstride;
+    float *xst = xst_all + (size_t)b * ubstride;
     const int *map = map_all + (size_t)b * np;
+    const int lcol = lane & 31, lhalf = lane >> 5;
+    const int ntiles = (kb / 32) * CTT;
 
     for (int i = tid; i < kb; i += NT) s_q[i] = map[C0 + i];
     __syncthreads();
-    for (int idx = tid; idx < kb * (CT / 4); idx += NT) {
-        const int k = idx / (CT / 4), c4 = (idx % (CT / 4)) * 4;
-        *reinterpret_cast<float4 *>(&s_x[k * LDX + c4]) =
-            *reinterpret_cast<const float4 *>(src + (size_t)s_q[k] * ld + col0 + c4);
+    // this wave's tiles of the pivot rows: from the working copy (through the row map) or from where the call for
+    // the earlier groups parked them
+    float16v acc[kStripTPW];
+#pragma unroll
+    for (int ti = 0; ti < kStripTPW; ++ti) {
+        const int t = wave + ti * (NT / 64);
+        if (t < ntiles) {
+            const int rt = t / CTT, col = col0 + (t % CTT) * 32 + lcol;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                acc[ti][reg] = (g_lo == 0) ? src[(size_t)s_q[r] * ld + col] : xst[(size_t)r * np + col];
+            }
+        }
     }
-    const int lcol = lane & 31, lhalf = lane >> 5;
-    // the multipliers of 16 steps, all kb pivot rows: requested one round ahead (registers), so that a round is the
+    // the multipliers of G steps, all kb pivot rows: requested one round ahead (registers), so that a round is the
     // strip and the update, not a dependent global round trip on top
-    constexpr int NL = kMaxBW * 4 / NT;
+    constexpr int NL = (kMaxBW * (G / 4) + NT - 1) / NT;
     float4 lreg[NL];
-    auto load_l = [&](int s16) {
+    auto load_l = [&](int s0) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int idx = tid + i * NT;
-            if (idx < kb * 4)
-                lreg[i] = *reinterpret_cast<const float4 *>(mf + (size_t)s_q[idx >> 2] * mf_ld + s16 + (idx & 3) * 4);
+            if (idx < kb * (G / 4))
+                lreg[i] = *reinterpret_cast<const float4 *>(mf + (size_t)s_q[idx / (G / 4)] * mf_ld + s0 + (idx % (G / 4)) * 4);
         }
     };
     auto store_l = [&]() {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int idx = tid + i * NT;
-            if (idx < kb * 4) {
-                const int k = idx >> 2, m4 = (idx & 3) * 4;
+            if (idx < kb * (G / 4)) {
+                const int k = idx / (G / 4), m4 = (idx % (G / 4)) * 4;
                 s_lt[(m4 + 0) * LT + k] = lreg[i].x;
                 s_lt[(m4 + 1) * LT + k] = lreg[i].y;
                 s_lt[(m4 + 2) * LT + k] = lreg[i].z;
@@ -1354,80 +1562,114 @@ __global__ __launch_bounds__(kStripThreads) void gj_block_strip_kernel(const flo
             }
         }
     };
-    // u_m of 16 steps -> the rank-bw update's B operand.  Stored one round late, in front of the next request for
+    // u_m of G steps -> the rank-bw update's B operand.  Stored one round late, in front of the next request for
     // multipliers: a wave's memory operations complete in order, and the wait for those multipliers at the end of a
     // round must not have to wait for a store issued a moment ago to be acknowledged.
-    auto store_u = [&](int s16) {
-        const float *su = s_u + ((s16 >> 4) & 1) * 16 * LDX;
-        for (int idx = tid; idx < 16 * (CT / 4); idx += NT) {
+    auto store_u = [&](int s0) {
+        const float *su = s_u + ((s0 / G) & 1) * G * LDX;
+        for (int idx = tid; idx < G * (CT / 4); idx += NT) {
             const int m = idx / (CT / 4), c4 = (idx % (CT / 4)) * 4;
-            *reinterpret_cast<float4 *>(ub + (size_t)(s16 + m) * np + col0 + c4) =
+            *reinterpret_cast<float4 *>(ub + (size_t)(s0 + m) * np + col0 + c4) =
                 *reinterpret_cast<const float4 *>(&su[m * LDX + c4]);
         }
     };
-    load_l(0);
+    // the rows [O, O + G) of a 32-row tile -> s_x (O a compile-time constant: no run-time index into the registers)
+    auto park_group = [&](auto OFF, int rt_o) {
+        constexpr int O = decltype(OFF)::value;
+#pragma unroll
+        for (int ti = 0; ti < kStripTPW; ++ti) {
+            const int t = wave + ti * (NT / 64);
+            if (t < ntiles && t / CTT == rt_o) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int r = (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                    if (r >= O && r < O + G) s_x[(r - O) * LDX + (t % CTT) * 32 + lcol] = acc[ti][reg];
+                }
+            }
+        }
+    };
+    load_l(g_lo * G);
     store_l();
-    for (int s16 = 0; s16 < kb; s16 += 16) {
-        float *su = s_u + ((s16 >> 4) & 1) * 16 * LDX;
-        if (s16 > 0) store_u(s16 - 16);
-        if (s16 + 16 < kb) load_l(s16 + 16);
-        __syncthreads();  // s_lt complete; s_x complete (first round: loaded, later: the previous round's update)
+    for (int gi = g_lo; gi < g_hi; ++gi) {
+        const int s0 = gi * G;
+        float *su = s_u + (gi & 1) * G * LDX;
+        if (gi > g_lo) store_u(s0 - G);
+        if (gi + 1 < g_hi) load_l(s0 + G);
+        {
+            const int rt_o = s0 / 32;
+            switch ((s0 % 32) / G) {  // 32 / G cases
+            case 0: park_group(std::integral_constant<int, 0>{}, rt_o); break;
+            case 1: park_group(std::integral_constant<int, (G < 32 ? G : 0)>{}, rt_o); break;
+            case 2: park_group(std::integral_constant<int, (2 * G < 32 ? 2 * G : 0)>{}, rt_o); break;
+            case 3: park_group(std::integral_constant<int, (3 * G < 32 ? 3 * G : 0)>{}, rt_o); break;
+            case 4: park_group(std::integral_constant<int, (4 * G < 32 ? 4 * G : 0)>{}, rt_o); break;
+            case 5: park_group(std::integral_constant<int, (5 * G < 32 ? 5 * G : 0)>{}, rt_o); break;
+            case 6: park_group(std::integral_constant<int, (6 * G < 32 ? 6 * G : 0)>{}, rt_o); break;
+            default: park_group(std::integral_constant<int, (7 * G < 32 ? 7 * G : 0)>{}, rt_o); break;
+            }
+        }
+        __syncthreads();  // the group's rows and s_lt are in LDS
         if (tid < 4 * CT) {
+            constexpr int CPT = G / 4;
             const int c = tid >> 2, q4 = tid & 3;
-            float x[4];
+            float x[CPT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = s_x[(s16 + 4 * q4 + j) * LDX + c];
-            strip_steps<16>(x, s_lt + s16, LT, q4, &su[c], LDX, std::make_integer_sequence<int, 16>{});
+            for (int j = 0; j < CPT; ++j) x[j] = s_x[(CPT * q4 + j) * LDX + c];
+            strip_steps<G>(x, s_lt + s0, LT, q4, &su[c], LDX, std::make_integer_sequence<int, G>{});
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s_x[(s16 + 4 * q4 + j) * LDX + c] = x[j];
+            for (int j = 0; j < CPT; ++j) s_x[(CPT * q4 + j) * LDX + c] = x[j];
         }
         __syncthreads();
-        // every other pivot row: x[k][c] = fmaf(-f_m[k], u_m[c], x[k][c]), m ascending, 32 x 32 tiles over the waves
-        const int ntiles = (kb / 32) * (CT / 32);
-        for (int t = wave; t < ntiles; t += NT / 64) {
-            const int rt = t / (CT / 32), ctl = t % (CT / 32);
-            float16v acc;
+        // the group's rows after their own sub-panel: where their accumulation starts in the rank-bw update
+        for (int idx = tid; idx < G * (CT / 4); idx += NT) {
+            const int k = idx / (CT / 4), c4 = (idx % (CT / 4)) * 4;
+            *reinterpret_cast<float4 *>(xs + (size_t)(s0 + k) * np + col0 + c4) =
+                *reinterpret_cast<const float4 *>(&s_x[k * LDX + c4]);
+        }
+        // every later pivot row: x[k][c] = fmaf(-f_m[k], u_m[c], x[k][c]), m ascending (rows of this and of earlier
+        // groups in a tile take the same instructions: they are never read again)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                acc[reg] = s_x[(rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf) * LDX + ctl * 32 + lcol];
+        for (int ti = 0; ti < kStripTPW; ++ti) {
+            const int t = wave + ti * (NT / 64);
+            if (t < ntiles && (t / CTT) * 32 + 32 > s0 + G) {
+                const int rt = t / CTT, ctl = t % CTT;
 #pragma unroll
-            for (int kk = 0; kk < 16; kk += 2) {
-                const float af = s_lt[(kk + lhalf) * LT + rt * 32 + lcol];
-                const float bf = su[(kk + lhalf) * LDX + ctl * 32 + lcol];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                if (r < s16 || r >= s16 + 16) s_x[r * LDX + ctl * 32 + lcol] = acc[reg];  // not the group's own rows
+                for (int kk = 0; kk < G; kk += 2) {
+                    const float af = s_lt[(kk + lhalf) * LT + rt * 32 + lcol];
+                    const float bf = su[(kk + lhalf) * LDX + ctl * 32 + lcol];
+                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[ti], 0, 0, 0);
+                }
             }
         }
-        __syncthreads();  // before s_lt is overwritten and s_x is read again
-        if (s16 + 16 < kb) store_l();
+        __syncthreads();  // before s_lt, s_x are overwritten
+        if (gi + 1 < g_hi) store_l();
     }
-    store_u(kb - 16);
-    // the pivot rows are rows C0 .. C0+kb-1 of the new order
-    for (int idx = tid; idx < kb * (CT / 4); idx += NT) {
-        const int k = idx / (CT / 4), c4 = (idx % (CT / 4)) * 4;
-        *reinterpret_cast<float4 *>(dst + (size_t)(C0 + k) * ld + col0 + c4) =
-            *reinterpret_cast<const float4 *>(&s_x[k * LDX + c4]);
-    }
-    // ... and their entries in the next block's first sub-panels go to the compact panel inputs as well
-    if (col0 + CT > ex.col && col0 < ex.col + ex.w * ex.count) {
-        for (int idx = tid; idx < CT * (kb / 4); idx += NT) {
-            const int c = idx / (kb / 4), k4 = (idx % (kb / 4)) * 4;
-            panel_export_store4(ex, tstride, b, np, col0 + c, C0 + k4, s_x[(k4 + 0) * LDX + c], s_x[(k4 + 1) * LDX + c],
-                                s_x[(k4 + 2) * LDX + c], s_x[(k4 + 3) * LDX + c]);
+    store_u((g_hi - 1) * G);
+    if (g_hi * G < kb) {  // the rows of the groups still to come: parked for the next call
+#pragma unroll
+        for (int ti = 0; ti < kStripTPW; ++ti) {
+            const int t = wave + ti * (NT / 64);
+            if (t < ntiles && (t / CTT) * 32 + 32 > g_hi * G) {
+                const int rt = t / CTT, col = col0 + (t % CTT) * 32 + lcol;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                    xst[(size_t)r * np + col] = acc[ti][reg];
+                }
+            }
         }
     }
 }
 
 // Gk[k][row] = mf[map[row]][k], k < kdim: the block's negated multipliers, transposed and in the new row order
 // (A operand of the rank-bw update); 64 x 64 tiles through LDS, both global sides coalesced.
+// The block's own pivot rows (rows C0 .. C0+kdim-1 of the new order) enter the update with the value the strip of
+// their sub-panel left (xs): everything up to the end of that sub-panel is applied already, so their multipliers of
+// those steps are replaced by 0 -- fmaf(0, u, x) == x -- and only the later sub-panels' steps reach them.
 __global__ __launch_bounds__(256) void gj_mult_transpose_kernel(const float *__restrict__ mf_all, size_t mfstride, int mf_ld,
                                                                  int np, const int *__restrict__ map_all,
-                                                                 float *__restrict__ gk_all, size_t gkstride,
-                                                                 const int *__restrict__ guard)
+                                                                 float *__restrict__ gk_all, size_t gkstride, int C0,
+                                                                 int kdim, int w, const int *__restrict__ guard)
 {
     __shared__ float t[64][65];
     __shared__ int s_q[64];
@@ -1443,7 +1685,12 @@ __global__ __launch_bounds__(256) void gj_mult_transpose_kernel(const float *__r
     for (int q = 0; q < 4; ++q) {
         const int r = (tid >> 4) + 16 * q, c4 = (tid & 15) * 4;
         const float4 v = *reinterpret_cast<const float4 *>(mf + (size_t)s_q[r] * mf_ld + k0 + c4);
-        t[r][c4] = v.x; t[r][c4 + 1] = v.y; t[r][c4 + 2] = v.z; t[r][c4 + 3] = v.w;
+        const int rel = row0 + r - C0;  // a pivot row of the block: steps below `lim` are applied already
+        const int lim = ((unsigned)rel < (unsigned)kdim) ? (rel / w + 1) * w : 0;
+        t[r][c4] = (k0 + c4 < lim) ? 0.0f : v.x;
+        t[r][c4 + 1] = (k0 + c4 + 1 < lim) ? 0.0f : v.y;
+        t[r][c4 + 2] = (k0 + c4 + 2 < lim) ? 0.0f : v.z;
+        t[r][c4 + 3] = (k0 + c4 + 3 < lim) ? 0.0f : v.w;
     }
     __syncthreads();
 #pragma unroll
@@ -1463,8 +1710,9 @@ template <int BK>
 __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__restrict__ src_all,
                                                               float *__restrict__ dst_all,
                                                               const float *__restrict__ mf_all, size_t mfstride, int mf_ld,
-                                                              const float *__restrict__ ub_all, size_t ubstride,
-                                                              int np, int ld, size_t mstride, int c0, int kdim,
+                                                              const float *__restrict__ ub_all,
+                                                              const float *__restrict__ xs_all, size_t ubstride,
+                                                              int np, int ld, size_t mstride, int c0, int kdim, int w,
                                                               int col_lo, const int *__restrict__ map_all,
                                                               PanelExport ex, size_t tstride,
                                                               const int *__restrict__ guard)
@@ -1484,12 +1732,15 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int row0 = blockIdx.y * BM;
-    if (row0 >= c0 && row0 < c0 + kdim) return;  // the block's pivot rows: written by gj_block_strip_kernel
+    // the block's own pivot rows start from what the strip of their sub-panel left (xs) and only take the later
+    // sub-panels' steps (see gj_mult_transpose_kernel)
+    const bool tile_in_block = (row0 >= c0 && row0 < c0 + kdim);
     const int col0 = col_lo + blockIdx.x * BN;
     const float *src = src_all + (size_t)b * mstride;
     float *dst = dst_all + (size_t)b * mstride;
     const float *mf = mf_all + (size_t)b * mfstride;
     const float *ub = ub_all + (size_t)b * ubstride;
+    const float *xs = xs_all + (size_t)b * ubstride;
     const int *map = map_all + (size_t)b * np;
 
     for (int i = tid; i < BM; i += 256) s_map[i] = map[row0 + i];
@@ -1503,7 +1754,7 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int lr = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-            acc[reg] = src[(size_t)s_map[lr] * ld + col];
+            acc[reg] = tile_in_block ? xs[(size_t)(row0 + lr - c0) * np + col] : src[(size_t)s_map[lr] * ld + col];
         }
     }
     for (int kt = 0; kt < kdim; kt += BK) {
@@ -1514,10 +1765,11 @@ __global__ __launch_bounds__(256) void gj_rank_update_kernel(const float *__rest
             if (idx < BM * BK / 4) {
                 const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
                 const float4 v = *reinterpret_cast<const float4 *>(mf + (size_t)s_map[rr] * mf_ld + kt + k4);
-                s_a[(k4 + 0) * LDA + rr] = v.x;
-                s_a[(k4 + 1) * LDA + rr] = v.y;
-                s_a[(k4 + 2) * LDA + rr] = v.z;
-                s_a[(k4 + 3) * LDA + rr] = v.w;
+                const int lim = tile_in_block ? ((row0 + rr - c0) / w + 1) * w : 0;
+                s_a[(k4 + 0) * LDA + rr] = (kt + k4 + 0 < lim) ? 0.0f : v.x;
+                s_a[(k4 + 1) * LDA + rr] = (kt + k4 + 1 < lim) ? 0.0f : v.y;
+                s_a[(k4 + 2) * LDA + rr] = (kt + k4 + 2 < lim) ? 0.0f : v.z;
+                s_a[(k4 + 3) * LDA + rr] = (kt + k4 + 3 < lim) ? 0.0f : v.w;
             }
         }
         // stage B: BK rows of u x BN columns
@@ -1621,11 +1873,14 @@ static hipError_t launch_subpanel(const SubpanelArgs &A, int nwgs, hipStream_t s
 //  * panel(s) alone: the smallest thread geometry that holds its rows (fewer waves and fewer rows per lane both
 //    shorten a pivot step);
 //  * update(t) alone: 256-thread workgroups, one tile each.
-static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelArgs &A, hipStream_t stream)
+static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelArgs &A0, hipStream_t stream)
 {
+    SubpanelArgs A = A0;
     const int tiles = A.upd_on ? (A.kb / 64) * (p.np / 64) : 0;
+    const int os_tiles = A.os_on ? A.batch * A.os_ntiles : 0;  // strip tiles of columns outside the block
     if (!A.panel_on) {
-        const dim3 grid(A.batch * tiles);
+        A.upd_wgs = A.batch * tiles;
+        const dim3 grid(A.upd_wgs + os_tiles);
         if (w == 32) hipLaunchKernelGGL((gj_inblock_update_kernel<32>), grid, dim3(256), 0, stream, A);
         else if (w == 16) hipLaunchKernelGGL((gj_inblock_update_kernel<16>), grid, dim3(256), 0, stream, A);
         else if (w == 8) hipLaunchKernelGGL((gj_inblock_update_kernel<8>), grid, dim3(256), 0, stream, A);
@@ -1635,18 +1890,19 @@ static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelA
     if (A.ngroups > 1) {  // multi-workgroup panel: never fused, W = 16 (what the plan gives every block then)
         if (A.upd_on || w != 16) return hipErrorInvalidValue;
         constexpr size_t lds = subpanel_lds_bytes<1024, 4, 16, false>();
-        // MI32_DEBUG_DROP_PANEL_GROUP=1 (tests only, host side only): the last workgroup of the grid is never
+        // MI32_DEBUG_DROP_PANEL_GROUP=1 (tests only, host side only): the last panel workgroup of the grid is never
         // launched, i.e. one panel loses a partner -- what a foreign kernel holding the CUs would cause
         const char *dv = std::getenv("MI32_DEBUG_DROP_PANEL_GROUP");
-        const int drop = dv ? std::atoi(dv) : 0;
-        hipLaunchKernelGGL((gj_panel_multi_kernel<16>), dim3(A.batch * A.ngroups - (drop ? 1 : 0)), dim3(1024), lds,
-                           stream, A);
+        A.drop_groups = (dv && std::atoi(dv)) ? 1 : 0;
+        hipLaunchKernelGGL((gj_panel_multi_kernel<16>), dim3(A.batch * A.ngroups - A.drop_groups + (os_tiles + 3) / 4),
+                           dim3(1024), lds, stream, A);
         return hipSuccess;
     }
     const bool fused = A.upd_on != 0;
     int nt, rpt;
     panel_geometry(p, p.np - A.row_lo, nt, rpt);
-    const int nwgs = A.batch + A.batch * (tiles / (nt / 256));
+    A.upd_wgs = A.batch * (tiles / (nt / 256));
+    const int nwgs = A.batch + A.upd_wgs + (os_tiles + nt / 256 - 1) / (nt / 256);
 #define MI32_SUBPANEL_CASE(T, R, WW)                                                                   \
     if (nt == T && rpt == R && w == WW && !fused) return launch_subpanel<T, R, WW, false>(A, nwgs, stream);
 #define MI32_SUBPANEL_FUSED(T, R, WW)                                                                  \
@@ -1677,6 +1933,47 @@ static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelA
 #endif
 #undef MI32_SUBPANEL_CASE
 #undef MI32_SUBPANEL_FUSED
+    return hipErrorInvalidValue;
+}
+
+template <int CT, int G>
+static hipError_t launch_block_strip_t(dim3 grid, size_t lds, hipStream_t st, const float *src, size_t mstride, int np, int ld,
+                                       const float *mf, size_t mfstride, int mf_ld, float *ub, float *xs, float *xst,
+                                       size_t ubstride, int C0, int kb, const int *map, int col_lo, int col_hi, int inside,
+                                       int g_lo, int g_hi, const int *guard)
+{
+    static std::once_flag once[64];  // function attributes are per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t e = hipSuccess;
+    std::call_once(once[dev & 63], [&] {
+        e = hipFuncSetAttribute((const void *)gj_block_strip_kernel<CT, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)block_strip_lds_bytes<CT, G>(CT == 64 ? 256 : kMaxBW));
+    });
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((gj_block_strip_kernel<CT, G>), grid, dim3(kStripThreads), lds, st, src, mstride, np, ld, mf, mfstride,
+                       mf_ld, ub, xs, xst, ubstride, C0, kb, map, col_lo, col_hi, inside, g_lo, g_hi, guard);
+    return hipSuccess;
+}
+// the block's strips, sub-panels [g_lo, g_hi), for the columns outside the block that lie in [col_lo, col_hi) (inside) /
+// that do not
+static hipError_t launch_block_strip(int w, int batch, hipStream_t st, const float *src, size_t mstride, int np, int ld,
+                                     const float *mf, size_t mfstride, int mf_ld, float *ub, float *xs, float *xst,
+                                     size_t ubstride, int C0, int kb, const int *map, int col_lo, int col_hi, int inside,
+                                     int g_lo, int g_hi, const int *guard)
+{
+#define MI32_STRIP_CASE(GG)                                                                                               \
+    if (w == GG) {                                                                                                        \
+        if (kb <= 256)                                                                                                    \
+            return launch_block_strip_t<64, GG>(dim3(np / 64, batch), block_strip_lds_bytes<64, GG>(kb), st, src, mstride, np, \
+                                                ld, mf, mfstride, mf_ld, ub, xs, xst, ubstride, C0, kb, map, col_lo, col_hi, \
+                                                inside, g_lo, g_hi, guard);                                               \
+        return launch_block_strip_t<32, GG>(dim3(np / 32, batch), block_strip_lds_bytes<32, GG>(kb), st, src, mstride, np, ld, \
+                                            mf, mfstride, mf_ld, ub, xs, xst, ubstride, C0, kb, map, col_lo, col_hi, inside, \
+                                            g_lo, g_hi, guard);                                                           \
+    }
+    MI32_STRIP_CASE(16) MI32_STRIP_CASE(8) MI32_STRIP_CASE(4) MI32_STRIP_CASE(32)
+#undef MI32_STRIP_CASE
     return hipErrorInvalidValue;
 }
 
@@ -1734,10 +2031,6 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                                       (int)rank_bw2_lds_bytes<MI32_BW_BK>(kMaxBW));
             (void)hipFuncSetAttribute((const void *)gj_rank_bw2_persistent_kernel<MI32_BW_BK>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-            (void)hipFuncSetAttribute((const void *)gj_block_strip_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)block_strip_lds_bytes<64>(256));
-            (void)hipFuncSetAttribute((const void *)gj_block_strip_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)block_strip_lds_bytes<32>(kMaxBW));
             attr_set = true;
         }
     }
@@ -1748,13 +2041,18 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
         if ((e = hipMemsetAsync(ws.xch, 0, (size_t)kXchGranules * sizeof(unsigned long long) * batch, stream)) != hipSuccess)
             return e;
     }
+    // MI32_STRIP_ONE_LAUNCH=1 (diagnostic): every block's strips in one launch at its end, no strip(t) tiles
+    const char *sol = std::getenv("MI32_STRIP_ONE_LAUNCH");
+    // GPU-filling batches: the strip(t) tiles (256-thread groups, one global round trip per 32 earlier steps) cost
+    // more than the one launch per block (measured 64 x 2048^2: 23.0 vs 21.7 ms)
+    const bool one_launch_strips = !lookahead && ((sol && std::atoi(sol) != 0) || batch * ((np + 63) / 64) > 256);
     float *cur = ws.m0, *oth = ws.m1;
     bool pending_b = false;  // a (B) half is in flight on the second stream
     int blk = 0, ev = 0;
     for (int C0 = 0; C0 < np; C0 += p.bw, ++blk) {
         const int kb = (C0 + p.bw <= np) ? p.bw : np - C0;
         int **rsb = &ws.rowsrc[2 * (blk & 1)];
-        float *mf = ws.mf[blk & 1], *ub = ws.ub[blk & 1];
+        float *mf = ws.mf[blk & 1], *ub = ws.ub[blk & 1], *xs = ws.xs[blk & 1];
         const int w = p.wblk[blk];                                       // sub-panel width of this block
         const int w_next = (blk + 1 < p.nblk) ? p.wblk[blk + 1] : w;     // ... and of the next one
         const int S = kb / w;                                            // sub-panels of this block (even)
@@ -1763,6 +2061,13 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
         // 3.06 ms, 1024^2 1.40 -> 1.27 ms); with more rows the prologue (rows x W x W fmaf on ONE CU) costs what
         // the update launch did (4096^2: 8.9 -> 9.5 ms), so those blocks keep panel(s) and update(s) apart.
         const bool fused = (np - C0) <= fused_rows;
+        // The strip(t) tiles follow the block sub-panel by sub-panel in the columns outside it -- unless the look-ahead
+        // is on: those columns are then still being written by the previous block's second-stream update while this
+        // block's panels run (the next block's columns too: half (A) of the previous block covered THIS block's), and
+        // the block's strips run in one launch at its end (gj_block_strip_kernel).
+        const int os_first = 0;
+        const int os_ntiles = (one_launch_strips || lookahead) ? 0 : (np - kb) / 64;
+        const bool strips_at_end = one_launch_strips || lookahead;
         float *x = cur, *y = oth;  // the block's panel columns alternate between the two copies
         for (int s = 0; s <= S; ++s) {
             SubpanelArgs P = {};   // the panel half
@@ -1819,8 +2124,19 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 const int tx = fused ? t + 2 : t + 1;
                 if (tx < S) U.u_exp = PanelExport{ws.pt[tx % 3], ws.pt_bstride, C0 + tx * w, w, 1};
             }
+            if (s > 0 && os_ntiles > 0) {
+                // strip(s-1) of the columns outside the block: rides in the launch of panel(s) (in the block's last
+                // in-block update for the last sub-panel); it needs panel(s-1)'s output and the strips before it
+                SubpanelArgs &O = (fused || s < S) ? P : U;
+                O.os_on = 1;
+                O.os_first = os_first; O.os_ntiles = os_ntiles;
+                O.os_cur = cur;
+                O.os_ub = ub; O.os_xs = xs; O.ubstride = ws.gkstride;
+                O.u_c0 = U.u_c0; O.C0 = C0; O.kb = kb;
+                O.u_mt = U.u_mt; O.u_submap = U.u_submap; O.u_rowsrc = U.u_rowsrc; O.u_mf = U.u_mf;
+            }
             if (fused) {
-                SubpanelArgs A = P;  // one launch: panel(s) || update(s-1)
+                SubpanelArgs A = P;  // one launch: panel(s) || update(s-1) || strip(s-1)
                 A.upd_on = U.upd_on; A.u_c0 = U.u_c0; A.u_has_prev = U.u_has_prev; A.u_above_hi = U.u_above_hi;
                 A.C0 = U.C0; A.kb = U.kb; A.x = U.x; A.y = U.y; A.u_gt = U.u_gt; A.u_submap = U.u_submap;
                 A.u_mt = U.u_mt; A.u_rowsrc = U.u_rowsrc; A.u_mf = U.u_mf;
@@ -1855,57 +2171,62 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 pending_b = false;
             }
             const bool split_update = lookahead && has_next;
-            // the pivot-row strip of the columns [lo, hi) (inside) or of all columns but those (outside)
-            auto launch_strip = [&](hipStream_t st, int lo, int hi, int inside, const PanelExport &pe) {
-                ProfScope ps(prof, KC_STRIP, st);
-                if (kb <= 256)
-                    hipLaunchKernelGGL((gj_block_strip_kernel<64>), dim3(np / 64, batch), dim3(kStripThreads),
-                                       block_strip_lds_bytes<64>(kb), st, cur, oth, ws.mstride, np, p.ld, mf, ws.mfstride,
-                                       p.bw, ub, ws.gkstride, C0, kb, rowsrc, lo, hi, inside, pe, ws.tstride, guard);
-                else
-                    hipLaunchKernelGGL((gj_block_strip_kernel<32>), dim3(np / 32, batch), dim3(kStripThreads),
-                                       block_strip_lds_bytes<32>(kb), st, cur, oth, ws.mstride, np, p.ld, mf, ws.mfstride,
-                                       p.bw, ub, ws.gkstride, C0, kb, rowsrc, lo, hi, inside, pe, ws.tstride, guard);
-            };
             auto launch_transpose = [&](hipStream_t st) {  // A operand of the rank-bw update, k-major (mi32_rank_bw.h)
                 ProfScope ps(prof, KC_TRANSPOSE, st);
                 hipLaunchKernelGGL(gj_mult_transpose_kernel, dim3(np / 64, kb / 64, batch), dim3(256), 0, st, mf,
-                                   ws.mfstride, p.bw, np, rowsrc, ws.gk, ws.gkstride, guard);
+                                   ws.mfstride, p.bw, np, rowsrc, ws.gk, ws.gkstride, C0, kb, w, guard);
             };
             if (split_update) {
                 {   // (A): the next block's columns, on the main stream; exports the next sub-panels
-                    launch_strip(stream, next, next + kb_next, 1, exn);
+                    {
+                        ProfScope ps(prof, KC_TRANSPOSE, stream);
+                        if ((e = launch_block_strip(w, batch, stream, cur, ws.mstride, np, p.ld, mf, ws.mfstride, p.bw, ub, xs,
+                                                    ws.xst, ws.gkstride, C0, kb, rowsrc, next, next + kb_next, 1, 0, S,
+                                                    guard)) != hipSuccess)
+                            return e;
+                    }
                     ProfScope ps(prof, KC_UPDATE_OUT, stream);
                     // small tiles: only kb_next columns, so 64x64 gives 4x the workgroups of 128x128
                     hipLaunchKernelGGL((gj_rank_update_kernel<32>), dim3(kb_next / 64, np / 64, batch), dim3(256), 0,
-                                       stream, cur, oth, mf, ws.mfstride, p.bw, ub, ws.gkstride, np, p.ld, ws.mstride, C0, kb,
-                                       next, rowsrc, exn, ws.tstride, guard);
+                                       stream, cur, oth, mf, ws.mfstride, p.bw, ub, xs, ws.gkstride, np, p.ld, ws.mstride, C0, kb,
+                                       w, next, rowsrc, exn, ws.tstride, guard);
                 }
                 // (B): everything else, on the second stream, after this block's panel phase
                 ev = (ev + 1) % (ex.n_events / 2);
                 hipEvent_t e_panel = ex.events[ex.n_events / 2 + ev];
                 if ((e = hipEventRecord(e_panel, stream)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(ex.aux, e_panel, 0)) != hipSuccess) return e;
-                launch_strip(ex.aux, next, next + kb_next, 0, no_export);
+                {   // the strips of every column the strip(t) tiles could not follow
+                    ProfScope ps(prof, KC_TRANSPOSE, ex.aux);
+                    if ((e = launch_block_strip(w, batch, ex.aux, cur, ws.mstride, np, p.ld, mf, ws.mfstride, p.bw, ub, xs,
+                                                ws.xst, ws.gkstride, C0, kb, rowsrc, next, next + kb_next, 0, 0, S,
+                                                guard)) != hipSuccess)
+                        return e;
+                }
                 launch_transpose(ex.aux);  // only half (B) reads the transposed multipliers: off the main stream
                 {
                     ProfScope ps(prof, KC_UPDATE_OUT, ex.aux);
                     // persistent flavour: aux_workgroups (< number of CUs) workgroups, with so much dynamic LDS
                     // that one CU holds at most one of them -> the remaining CUs stay free for the main stream
                     hipLaunchKernelGGL((gj_rank_bw2_persistent_kernel<MI32_BW_BK>), dim3(ex.aux_workgroups, batch),
-                                       dim3(256), lds_persistent, ex.aux, cur, oth, x, ws.mstride, ws.gk, ws.gkstride, ub, np,
+                                       dim3(256), lds_persistent, ex.aux, cur, oth, x, ws.mstride, ws.gk, ws.gkstride, ub, xs, np,
                                        p.ld, ws.mstride, C0, kb, rowsrc, copy, no_export, ws.tstride, next,
                                        next + kb_next, guard);
                 }
                 if ((e = hipEventRecord(ex.events[ev], ex.aux)) != hipSuccess) return e;
                 pending_b = true;
             } else {
-                launch_strip(stream, 0, np, 1, exn);
+                if (strips_at_end) {  // no strip(t) tiles ran
+                    ProfScope ps(prof, KC_TRANSPOSE, stream);
+                    if ((e = launch_block_strip(w, batch, stream, cur, ws.mstride, np, p.ld, mf, ws.mfstride, p.bw, ub, xs,
+                                                ws.xst, ws.gkstride, C0, kb, rowsrc, 0, 0, 0, 0, S, guard)) != hipSuccess)
+                        return e;
+                }
                 launch_transpose(stream);
                 ProfScope ps(prof, KC_UPDATE_OUT, stream);
                 hipLaunchKernelGGL((gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS, 128, (MI32_BW_PF != 0)>), dim3((np / 128) * (np / 128), batch),
                                    dim3(256), rank_bw2_lds_bytes<MI32_BW_BK>(kb), stream, cur, oth, x, ws.mstride, ws.gk,
-                                   ws.gkstride, ub, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, exn, ws.tstride, 0, 0, guard);
+                                   ws.gkstride, ub, xs, np, p.ld, ws.mstride, C0, kb, rowsrc, copy, exn, ws.tstride, 0, 0, guard);
             }
             float *t = cur; cur = oth; oth = t;
         } else {

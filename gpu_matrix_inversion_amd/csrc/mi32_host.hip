@@ -756,7 +756,7 @@ static void fill_times10(double *times10, const double *ms, std::chrono::steady_
     // fused step launches of the sweep path are accounted to the column slot, where the reference spends its time
     times10[4] = ms[KC_PANEL] * 1e-3;
     times10[5] = 0.0;  // fixRow has no launch of its own
-    times10[6] = (ms[KC_SWEEP_STEP] + ms[KC_UPDATE_IN] + ms[KC_UPDATE_OUT] + ms[KC_TRANSPOSE] + ms[KC_STRIP]) * 1e-3;
+    times10[6] = (ms[KC_SWEEP_STEP] + ms[KC_UPDATE_IN] + ms[KC_UPDATE_OUT] + ms[KC_TRANSPOSE]) * 1e-3;
     times10[7] = sec(t1, t2);
     times10[8] = ms[KC_FINISH] * 1e-3 + sec(t2, t3);
     times10[9] = sec(tq0, t3);

@@ -47,8 +47,7 @@ enum KernelClass {
     KC_UPDATE_OUT = 4, // rank-bw update of the rest of the matrix (fp32 MFMA)
     KC_FINISH = 5,     // getInverted counterpart (column un-permutation)
     KC_TRANSPOSE = 6,  // multiplier transposition in front of a rank-bw update (A operand, k-major)
-    KC_STRIP = 7,      // the block's pivot-row strip in front of a rank-bw update (B operand)
-    KC_COUNT = 8
+    KC_COUNT = 7
 };
 struct Profiler {
     virtual void begin(int kclass, hipStream_t s) = 0;

@@ -148,9 +148,9 @@ __device__ __forceinline__ void rank_bw2_tail(F &k_tile, int pf0)
 template <int BK, int BN = 128, bool PF = false>
 __device__ __forceinline__ void rank_bw2_tile(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
-    const float *__restrict__ gk_all, size_t gkstride, const float *__restrict__ ub_all, int np, int ld, size_t mstride,
-    int c0, int kdim, const int *__restrict__ map_all, int copy_panel, const PanelExport &ex, size_t tstride, int skip_lo,
-    int skip_hi, int b, int rt, int ct, float *rb_smem)
+    const float *__restrict__ gk_all, size_t gkstride, const float *__restrict__ ub_all, const float *__restrict__ xs_all,
+    int np, int ld, size_t mstride, int c0, int kdim, const int *__restrict__ map_all, int copy_panel,
+    const PanelExport &ex, size_t tstride, int skip_lo, int skip_hi, int b, int rt, int ct, float *rb_smem)
 {
     constexpr int BM = 128;
     constexpr int TN = BN / 64;          // 32-column MFMA tiles per wave
@@ -171,6 +171,7 @@ __device__ __forceinline__ void rank_bw2_tile(
     float *dst = dst_all + (size_t)b * mstride;
     const float *gk = gk_all + (size_t)b * gkstride;
     const float *ub = ub_all + (size_t)b * gkstride;
+    const float *xs = xs_all + (size_t)b * gkstride;
     const int *map = map_all + (size_t)b * np;
 
     if (col0 >= skip_lo && col0 < skip_hi) return;
@@ -185,9 +186,10 @@ __device__ __forceinline__ void rank_bw2_tile(
         }
         return;
     }
-    // Block bounds are multiples of 128, so a whole tile is either inside the block or outside it: the block's own
-    // pivot rows were finished by gj_block_strip_kernel
-    if (row0 >= c0 && row0 < c0 + kdim) return;
+    // Block bounds are multiples of 128, so a whole tile is either inside the block or outside it.  The block's own
+    // pivot rows start from what the strip of their sub-panel left (xs[k][col], k-major like ub) and only take the
+    // later sub-panels' steps: gj_mult_transpose_kernel has zeroed their other multipliers.
+    const bool tile_in_block = (row0 >= c0 && row0 < c0 + kdim);
 
     MI32_RB_STAMP(0);
     if (tid < BM) s_map[tid] = map[row0 + tid];
@@ -221,7 +223,7 @@ __device__ __forceinline__ void rank_bw2_tile(
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                acc[tm][tn][reg] = src[(size_t)s_map[lr] * ld + col];
+                acc[tm][tn][reg] = tile_in_block ? xs[(size_t)(row0 + lr - c0) * np + col] : src[(size_t)s_map[lr] * ld + col];
             }
         }
     MI32_RB_STAMP(1);
@@ -293,15 +295,15 @@ __device__ __forceinline__ void rank_bw2_tile(
 template <int BK, int WPS, int BN = 128, bool PF = false>
 __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
-    const float *__restrict__ gk_all, size_t gkstride, const float *__restrict__ ub_all, int np, int ld, size_t mstride,
-    int c0, int kdim, const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo,
-    int skip_hi, const int *__restrict__ guard)
+    const float *__restrict__ gk_all, size_t gkstride, const float *__restrict__ ub_all, const float *__restrict__ xs_all,
+    int np, int ld, size_t mstride, int c0, int kdim, const int *__restrict__ map_all, int copy_panel, PanelExport ex,
+    size_t tstride, int skip_lo, int skip_hi, const int *__restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) float rb_smem[];
     if (guard != nullptr && __builtin_amdgcn_readfirstlane(guard[blockIdx.y]) == MI32_RUNTIME_ERROR) return;  // given up
     int rt, ct;
     rb_tile_of(blockIdx.x, np / 128, np / BN, rt, ct);
-    rank_bw2_tile<BK, BN, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, ub_all, np, ld, mstride, c0, kdim,
+    rank_bw2_tile<BK, BN, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, ub_all, xs_all, np, ld, mstride, c0, kdim,
                               map_all, copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
 }
 
@@ -313,9 +315,9 @@ __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
 template <int BK, bool PF = false>
 __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
     const float *__restrict__ src_all, float *__restrict__ dst_all, const float *__restrict__ g_all, size_t gstride,
-    const float *__restrict__ gk_all, size_t gkstride, const float *__restrict__ ub_all, int np, int ld, size_t mstride,
-    int c0, int kdim, const int *__restrict__ map_all, int copy_panel, PanelExport ex, size_t tstride, int skip_lo,
-    int skip_hi, const int *__restrict__ guard)
+    const float *__restrict__ gk_all, size_t gkstride, const float *__restrict__ ub_all, const float *__restrict__ xs_all,
+    int np, int ld, size_t mstride, int c0, int kdim, const int *__restrict__ map_all, int copy_panel, PanelExport ex,
+    size_t tstride, int skip_lo, int skip_hi, const int *__restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) float rb_smem[];
     if (guard != nullptr && __builtin_amdgcn_readfirstlane(guard[blockIdx.y]) == MI32_RUNTIME_ERROR) return;  // given up
@@ -323,8 +325,8 @@ __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
     for (int id = blockIdx.x; id < T * T; id += gridDim.x) {
         int rt, ct;
         rb_tile_of(id, T, T, rt, ct);
-        rank_bw2_tile<BK, 128, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, ub_all, np, ld, mstride, c0, kdim,
-                                   map_all, copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
+        rank_bw2_tile<BK, 128, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, ub_all, xs_all, np, ld, mstride, c0,
+                                   kdim, map_all, copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
         __syncthreads();  // the next tile re-uses the LDS buffers and maps
     }
 }

@@ -118,9 +118,8 @@ int mi32_residual_device(mi32_handle_t h, const float *d_a, const float *d_x, in
  * per kernel class, the summed milliseconds and the number of launches since the last
  * call.  Classes (MI32_KC_*): 0 init (makeAugmented), 1 sweep step, 2 panel steps,
  * 3 in-block rank-w update, 4 rank-bw update (fp32 MFMA), 5 finish (getInverted),
- * 6 multiplier transposition in front of each rank-bw update (its A operand), 7 the block's pivot-row strip in
- * front of each rank-bw update (its B operand). */
-#define MI32_KC_COUNT 8
+ * 6 multiplier transposition in front of each rank-bw update (its A operand). */
+#define MI32_KC_COUNT 7
 int mi32_set_profiling(mi32_handle_t h, int enable);
 int mi32_get_profile(mi32_handle_t h, double *ms_per_class, long long *launches_per_class, int nclasses);
 
