@@ -30,6 +30,7 @@ KERNEL_CLASSES = ("init", "sweep_step", "panel", "update_in_block", "update_rank
 C_ABI_SYMBOLS = (
     "mi32_matrix_inv_32",
     "mi32_matrix_inv_32_batched",
+    "mi32_matrix_inv_32_batched_multi",
     "mi32_create",
     "mi32_destroy",
     "mi32_set_stream",
@@ -111,6 +112,10 @@ def load() -> ctypes.CDLL:
     lib.mi32_matrix_inv_32.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp]
     lib.mi32_matrix_inv_32_batched.restype = ctypes.c_int
     lib.mi32_matrix_inv_32_batched.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ip]
+    lib.mi32_debug_drop_panel_group.restype = ctypes.c_int
+    lib.mi32_debug_drop_panel_group.argtypes = [ctypes.c_int]
+    lib.mi32_matrix_inv_32_batched_multi.restype = ctypes.c_int
+    lib.mi32_matrix_inv_32_batched_multi.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ip, ctypes.c_int]
     lib.mi32_create.restype = ctypes.c_int
     lib.mi32_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
     lib.mi32_destroy.restype = ctypes.c_int

@@ -97,8 +97,10 @@ def matrix_inversion_no_pivots(matrix_vector, matrix_order: int) -> np.ndarray:
     return np.empty(0, dtype=np.float64)
 
 
-def matrix_inv_32_batched(a: np.ndarray):
-    """Host batch (B, N, N) -> (inverses (B, N, N), status int32[B])."""
+def matrix_inv_32_batched(a: np.ndarray, ngpus: int = 1):
+    """Host batch (B, N, N) -> (inverses (B, N, N), status int32[B]).  ``ngpus`` != 1: the batch is sharded over that
+    many GPUs of this node (0 = all visible) inside the library, one host thread and context per GPU
+    (``mi32_matrix_inv_32_batched_multi``): no launcher, no torch.distributed."""
     lib = _lib.load()
     a = np.ascontiguousarray(a, dtype=np.float32)
     if a.ndim != 3 or a.shape[1] != a.shape[2] or a.shape[0] == 0 or a.shape[1] == 0:
@@ -107,8 +109,14 @@ def matrix_inv_32_batched(a: np.ndarray):
     out = np.empty_like(a)
     st = np.empty(b, dtype=np.int32)
     fp = ctypes.POINTER(ctypes.c_float)
-    rc = lib.mi32_matrix_inv_32_batched(a.ctypes.data_as(fp), n, b, out.ctypes.data_as(fp),
-                                        st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if ngpus != 1:
+        rc = lib.mi32_matrix_inv_32_batched_multi(a.ctypes.data_as(fp), n, b, out.ctypes.data_as(fp),
+                                                  st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), int(ngpus))
+        if rc == _lib.MI32_BAD_SHAPE:
+            raise ValueError("more GPUs asked for than are visible")
+    else:
+        rc = lib.mi32_matrix_inv_32_batched(a.ctypes.data_as(fp), n, b, out.ctypes.data_as(fp),
+                                            st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
     if rc == _lib.MI32_RUNTIME_ERROR:
         raise Mi32Error(lib.mi32_last_error().decode())
     return out, st

@@ -50,6 +50,7 @@
 // with an identity block to a multiple of 128 so that no tile needs bounds
 // checks: inv(diag(A, I)) = diag(inv(A), I); a real column only ever takes its
 // pivot from the real rows, so the padding is never swapped into the matrix.
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <utility>
@@ -1848,20 +1849,28 @@ __global__ __launch_bounds__(256) void unpermute_columns_ld_kernel(const float *
 }
 
 
+// tests only: leave the last panel workgroup of every multi-workgroup panel launch out (see dispatch_subpanel)
+static std::atomic<int> g_debug_drop_panel_group{0};
+extern "C" int mi32_debug_drop_panel_group(int enable)
+{
+    g_debug_drop_panel_group.store(enable ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+
 template <int NT, int RPT, int W, bool FUSED>
 static hipError_t launch_subpanel(const SubpanelArgs &A, int nwgs, hipStream_t stream)
 {
     constexpr size_t lds = subpanel_lds_bytes<NT, RPT, W, FUSED>();
-    if (lds > 48 * 1024) {  // more dynamic LDS than the default limit: raise it once per device
-        static bool attr_set_dev[64] = {};
+    if (lds > 48 * 1024) {  // more dynamic LDS than the default limit: raise it once per device (any thread may be first)
+        static std::once_flag once[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (!attr_set_dev[dev & 63]) {
-            hipError_t e = hipFuncSetAttribute((const void *)gj_subpanel_kernel<NT, RPT, W, FUSED>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set_dev[dev & 63] = true;
-        }
+        hipError_t e = hipSuccess;
+        std::call_once(once[dev & 63], [&] {
+            e = hipFuncSetAttribute((const void *)gj_subpanel_kernel<NT, RPT, W, FUSED>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((gj_subpanel_kernel<NT, RPT, W, FUSED>), dim3(nwgs), dim3(NT), lds, stream, A);
     return hipSuccess;
@@ -1890,10 +1899,9 @@ static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelA
     if (A.ngroups > 1) {  // multi-workgroup panel: never fused, W = 16 (what the plan gives every block then)
         if (A.upd_on || w != 16) return hipErrorInvalidValue;
         constexpr size_t lds = subpanel_lds_bytes<1024, 4, 16, false>();
-        // MI32_DEBUG_DROP_PANEL_GROUP=1 (tests only, host side only): the last panel workgroup of the grid is never
+        // mi32_debug_drop_panel_group(1) (tests only, host side only): the last panel workgroup of the grid is never
         // launched, i.e. one panel loses a partner -- what a foreign kernel holding the CUs would cause
-        const char *dv = std::getenv("MI32_DEBUG_DROP_PANEL_GROUP");
-        A.drop_groups = (dv && std::atoi(dv)) ? 1 : 0;
+        A.drop_groups = g_debug_drop_panel_group.load(std::memory_order_relaxed) ? 1 : 0;
         hipLaunchKernelGGL((gj_panel_multi_kernel<16>), dim3(A.batch * A.ngroups - A.drop_groups + (os_tiles + 3) / 4),
                            dim3(1024), lds, stream, A);
         return hipSuccess;
@@ -2021,18 +2029,18 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     // runs).  Where the half is short against the panel phase (up to ~8192 rows) it gets fewer CUs, all to itself.
     const size_t lds_persistent = (ex.aux_exclusive ? 156 : 84) * 1024;
     {
-        static bool attr_set_dev[64] = {};  // function attributes are per device
+        static std::once_flag once[64];  // function attributes are per device; any thread may be the first
         int dev = 0;
         (void)hipGetDevice(&dev);
-        bool &attr_set = attr_set_dev[dev & 63];
-        if (!attr_set) {
+        std::call_once(once[dev & 63], [] {
             (void)hipFuncSetAttribute((const void *)gj_rank_bw2_kernel<MI32_BW_BK, MI32_BW_WPS, 128, (MI32_BW_PF != 0)>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)rank_bw2_lds_bytes<MI32_BW_BK>(kMaxBW));
             (void)hipFuncSetAttribute((const void *)gj_rank_bw2_persistent_kernel<MI32_BW_BK>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-            attr_set = true;
-        }
+            (void)hipFuncSetAttribute((const void *)gj_panel_multi_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)subpanel_lds_bytes<1024, 4, 16, false>());
+        });
     }
     // plans with shared panels: every launch skips a matrix whose panel lost a partner (SubpanelArgs::guard)
     const int *guard = p.multi_panel ? d_status : nullptr;

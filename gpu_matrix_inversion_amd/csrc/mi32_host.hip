@@ -18,6 +18,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include "mat_inv_32.h"
 #include "mat_inv_64.h"
 #include "mat_inv_bench.h"
@@ -766,76 +768,69 @@ static void fill_times10(double *times10, const double *ms, std::chrono::steady_
 // res_struct.h:4-6 -- [0] queue/context, [1] buffers (+ the H2D copy the reference's CL_MEM_COPY_HOST_PTR does),
 // [2] program build, [3] makeAugmented, [4] pivot, [5] row, [6] column, [7] compute, [8] getInverted (+ D2H),
 // [9] total; seconds.  The per-phase slots come from HIP events on the launch stream (mi32_set_profiling).
-// First touch of a large, freshly allocated result buffer on several threads: the kernel hands out zeroed pages one fault
-// at a time (64 MiB: ~12 ms on one thread of the MI355X host, ~2 ms on eight).
-static void parallel_first_touch(void *p, size_t bytes)
-{
-    const size_t kMin = (size_t)8 << 20;
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
-    if (bytes < 2 * kMin || nt == 1) { std::memset(p, 0, bytes); return; }
-    const size_t chunk = ((bytes / nt) + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    for (unsigned i = 1; i < nt; ++i) {
-        const size_t lo = (size_t)i * chunk;
-        if (lo >= bytes) break;
-        const size_t len = (lo + chunk <= bytes) ? chunk : bytes - lo;
-        try { th.emplace_back([=] { std::memset((char *)p + lo, 0, len); }); } catch (...) { std::memset((char *)p + lo, 0, len); }
-    }
-    std::memset(p, 0, chunk < bytes ? chunk : bytes);
-    for (auto &t : th) t.join();
-}
-
-// The caller's output buffer is write-only to us and often fresh from the allocator (numpy.empty, a new vector):
-// one store per page on several threads, while the device works, takes the page faults out of the copy back.
-static void parallel_page_touch(void *p, size_t bytes)
+// Pre-faulting of a large host buffer on several threads, WITHOUT writing to it: madvise(MADV_POPULATE_WRITE) makes
+// the kernel install writable pages (zero pages for fresh memory, the present contents otherwise) -- the buffer's
+// bytes, and any C++ object that lives or will live there, are never touched by us.  The kernel hands out pages one
+// fault at a time: 64 MiB cost ~12 ms on one thread of the MI355X host, ~2 ms on eight.  Used (a) on the result
+// vector's reserved storage before it is value-initialised and (b) on the caller's output buffer while the device
+// works -- which therefore keeps its contents until the copy back (mat_inv_32_c.h: "written only on MI32_OK /
+// MI32_SINGULAR").  Where the kernel does not know the advice the pages are faulted by the copy itself, as before.
+static void parallel_populate(void *p, size_t bytes)
 {
     const size_t kPage = 4096, kMin = (size_t)8 << 20;
     if (bytes < kMin) return;
+    const uintptr_t lo = ((uintptr_t)p + kPage - 1) & ~(uintptr_t)(kPage - 1);
+    const uintptr_t hi = ((uintptr_t)p + bytes) & ~(uintptr_t)(kPage - 1);
+    if (hi <= lo) return;
     unsigned nt = std::thread::hardware_concurrency();
     nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
-    char *base = (char *)p;
-    const size_t chunk = ((bytes / nt) + kPage - 1) & ~(kPage - 1);
-    auto touch = [=](size_t lo, size_t hi) {
-        // the first 4-byte-aligned location of every page in [lo, hi)
-        for (size_t off = lo; off < hi; off += kPage) {
-            volatile char *q = base + off;
-            *q = 0;
-        }
+    const size_t span = hi - lo;
+    const size_t chunk = ((span / nt) + kPage - 1) & ~(kPage - 1);
+    auto populate = [](uintptr_t a, size_t len) {
+#ifdef MADV_POPULATE_WRITE
+        (void)madvise(reinterpret_cast<void *>(a), len, MADV_POPULATE_WRITE);
+#else
+        (void)a; (void)len;
+#endif
     };
     std::vector<std::thread> th;
     for (unsigned i = 1; i < nt; ++i) {
-        const size_t lo = (size_t)i * chunk;
-        if (lo >= bytes) break;
-        const size_t hi = (lo + chunk <= bytes) ? lo + chunk : bytes;
-        try { th.emplace_back(touch, lo, hi); } catch (...) { touch(lo, hi); }
+        const size_t off = (size_t)i * chunk;
+        if (off >= span) break;
+        const size_t len = (off + chunk <= span) ? chunk : span - off;
+        try { th.emplace_back(populate, lo + off, len); } catch (...) { populate(lo + off, len); }
     }
-    touch(0, chunk < bytes ? chunk : bytes);
+    populate(lo, chunk < span ? chunk : span);
     for (auto &t : th) t.join();
 }
+
+// Error returns of the host-pointer paths leave the context as they found it.
+struct ProfilingGuard {
+    mi32_context *h = nullptr;
+    ~ProfilingGuard() { if (h) (void)mi32_set_profiling(h, 0); }
+};
 
 // `late_out`: where the result goes is only asked for once the kernels are queued -- the std::vector entry points
 // allocate and first-touch their 4 N^2 result bytes (64 MiB of page faults at N = 4096, ~8 ms) while the device works
 typedef void *(*LateOut)(void *ctx);
-static int host_invert_32(const float *a, int n, int batch, float *inv, int *status, double *times10,
-                          LateOut late_out = nullptr, void *late_ctx = nullptr)
+// One host-pointer inversion on context h; the caller holds the lock that guards h's staging buffers.
+// total_s / compute_s: the reference's two numbers ("Tempo Totale Impiegato" / "Tempo Computazione", mat_inv_32.cpp:385-386).
+static int host_invert_32_on(mi32_context *h, std::chrono::steady_clock::time_point tq0, const float *a, int n, int batch,
+                             float *inv, int *status, double *times10, LateOut late_out, void *late_ctx, double *total_s,
+                             double *compute_s)
 {
-    if (!a || (!inv && !late_out) || n <= 0 || batch <= 0) return MI32_BAD_SHAPE;
-    const auto tq0 = std::chrono::steady_clock::now();
-    mi32_context *h = nullptr;
-    int rc = default_context(&h);  // the reference's platform / device / context / queue bring-up (cached here)
-    if (rc != MI32_OK) return rc;
-    std::lock_guard<std::mutex> lk(g_host_call_mu);  // one host-pointer call at a time: the staging buffers are shared
     const auto t0 = std::chrono::steady_clock::now();
     MI32_HIP(hipSetDevice(h->device));
     const size_t floats = (size_t)batch * n * n;
-    rc = ensure_io(h, floats, (size_t)batch);
+    int rc = ensure_io(h, floats, (size_t)batch);
     if (rc != MI32_OK) return rc;
+    ProfilingGuard prof_guard;  // profiling is switched off again on every way out
     if (times10) {
         rc = mi32_reserve(h, n, batch);  // workspace allocation belongs to the "buffers" slot
         if (rc != MI32_OK) return rc;
         rc = mi32_set_profiling(h, 1);
         if (rc != MI32_OK) return rc;
+        prof_guard.h = h;
         double ms[KC_COUNT]; long long cnt[KC_COUNT];
         (void)mi32_get_profile(h, ms, cnt, KC_COUNT);  // drop what an earlier call left
     }
@@ -848,7 +843,7 @@ static int host_invert_32(const float *a, int n, int batch, float *inv, int *sta
         inv = static_cast<float *>(late_out(late_ctx));
         if (!inv) { (void)hipStreamSynchronize(h->stream); return MI32_RUNTIME_ERROR; }
     } else {
-        parallel_page_touch(inv, floats * sizeof(float));  // the device is busy for the next milliseconds
+        parallel_populate(inv, floats * sizeof(float));  // the device is busy for the next milliseconds
     }
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t2 = std::chrono::steady_clock::now();
@@ -858,12 +853,11 @@ static int host_invert_32(const float *a, int n, int batch, float *inv, int *sta
     if (rc != MI32_OK) return rc;
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t3 = std::chrono::steady_clock::now();
-    g_last_total = std::chrono::duration<double>(t3 - t0).count();
-    g_last_compute = std::chrono::duration<double>(t2 - t1).count();
+    if (total_s) *total_s = std::chrono::duration<double>(t3 - t0).count();
+    if (compute_s) *compute_s = std::chrono::duration<double>(t2 - t1).count();
     if (times10) {
         double ms[KC_COUNT]; long long cnt[KC_COUNT];
         rc = mi32_get_profile(h, ms, cnt, KC_COUNT);
-        (void)mi32_set_profiling(h, 0);
         if (rc != MI32_OK) return rc;
         fill_times10(times10, ms, tq0, t0, t1, t2, t3);
     }
@@ -875,11 +869,117 @@ static int host_invert_32(const float *a, int n, int batch, float *inv, int *sta
     if (worst == MI32_RUNTIME_ERROR)  // the only status-borne runtime error (mi32_blocked.hip, shared panels)
         g_last_error = "a workgroup of a shared panel timed out waiting for its partners (the device was not ours "
                        "alone); the affected inverse is NaN-filled -- retry, or set MI32_MULTI_PANEL=0";
+    return worst;
+}
+
+static void print_reference_timing_lines()
+{
     if (env_int("MI32_VERBOSE", 0)) {
         // the reference's two stdout lines (mat_inv_32.cpp:385-386)
         std::printf("Tempo Totale Impiegato: %g seconds\nTempo Computazione: %g seconds\n", g_last_total,
                     g_last_compute);
         std::fflush(stdout);
+    }
+}
+
+static int host_invert_32(const float *a, int n, int batch, float *inv, int *status, double *times10,
+                          LateOut late_out = nullptr, void *late_ctx = nullptr)
+{
+    if (!a || (!inv && !late_out) || n <= 0 || batch <= 0) return MI32_BAD_SHAPE;
+    const auto tq0 = std::chrono::steady_clock::now();
+    mi32_context *h = nullptr;
+    int rc = default_context(&h);  // the reference's platform / device / context / queue bring-up (cached here)
+    if (rc != MI32_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_host_call_mu);  // one host-pointer call at a time: the staging buffers are shared
+    rc = host_invert_32_on(h, tq0, a, n, batch, inv, status, times10, late_out, late_ctx, &g_last_total, &g_last_compute);
+    if (rc == MI32_OK || rc == MI32_SINGULAR || rc == MI32_RUNTIME_ERROR) print_reference_timing_lines();
+    return rc;
+}
+
+// ---- the batch over several GPUs (what replaces the reference's platforms[0] / devices[0],
+//      mat_inv_32.cpp:239-244) -------------------------------------------------------------------------
+// One context and one host thread per GPU; GPU g owns the matrices [g * ceil(B / G), min(B, (g + 1) * ceil(B / G)))
+// and copies ITS OWN shard host -> device, inverts it and copies it back: no data-path exchange between the GPUs,
+// the worst status word is the return value.  The contexts are created on first use and kept.
+// MI32_MULTI_OVERSUBSCRIBE=1 (tests, single-GPU hosts): logical GPU g runs on device g % (visible devices), each with
+// a context of its own -- the threading, the ragged shards and the status reduction run exactly as on a real node.
+namespace {
+struct MultiSlot {
+    mi32_context *h = nullptr;
+    std::mutex mu;  // guards h's staging buffers, like g_host_call_mu guards the default context's
+};
+std::mutex g_multi_mu;                 // guards the table
+std::vector<MultiSlot *> g_multi;      // logical GPU -> slot (never shrinks; slots are never freed)
+}  // namespace
+
+extern "C" int mi32_matrix_inv_32_batched_multi(const float *a, int n, int batch, float *inv, int *status, int ngpus)
+{
+    if (!a || !inv || n <= 0 || batch <= 0) return MI32_BAD_SHAPE;
+    const auto tq0 = std::chrono::steady_clock::now();
+    int visible = 0;
+    MI32_HIP(hipGetDeviceCount(&visible));
+    if (visible <= 0) {
+        g_last_error = "no HIP device visible";
+        return MI32_RUNTIME_ERROR;
+    }
+    const bool oversub = env_int("MI32_MULTI_OVERSUBSCRIBE", 0) != 0;
+    if (ngpus <= 0) ngpus = visible;
+    if (ngpus > visible && !oversub) {
+        g_last_error = "mi32_matrix_inv_32_batched_multi: more GPUs asked for than are visible";
+        return MI32_BAD_SHAPE;
+    }
+    if (ngpus > batch) ngpus = batch;  // at least one matrix per GPU
+    const int per = (batch + ngpus - 1) / ngpus;  // ceil(B / G) matrices per GPU
+    std::vector<MultiSlot *> slots((size_t)ngpus, nullptr);
+    {
+        std::lock_guard<std::mutex> lk(g_multi_mu);
+        while ((int)g_multi.size() < ngpus) g_multi.push_back(new (std::nothrow) MultiSlot());
+        for (int g = 0; g < ngpus; ++g) {
+            if (!g_multi[(size_t)g]) return MI32_RUNTIME_ERROR;
+            slots[(size_t)g] = g_multi[(size_t)g];
+        }
+    }
+    std::vector<int> rcs((size_t)ngpus, MI32_OK);
+    std::vector<std::string> errs((size_t)ngpus);
+    std::vector<double> tot((size_t)ngpus, 0.0), cmp((size_t)ngpus, 0.0);
+    const size_t mat = (size_t)n * n;
+    auto work = [&](int g) {
+        const int lo = g * per, hi = (lo + per < batch) ? lo + per : batch;
+        if (lo >= hi) return;  // ragged tail: this GPU has nothing
+        MultiSlot *sl = slots[(size_t)g];
+        std::lock_guard<std::mutex> lk(sl->mu);
+        int rc = MI32_OK;
+        if (!sl->h) {
+            mi32_handle_t nh = nullptr;
+            rc = mi32_create(&nh, g % visible);
+            if (rc == MI32_OK) sl->h = nh;
+        }
+        if (rc == MI32_OK)
+            rc = host_invert_32_on(sl->h, tq0, a + (size_t)lo * mat, n, hi - lo, inv + (size_t)lo * mat,
+                                   status ? status + lo : nullptr, nullptr, nullptr, nullptr, &tot[(size_t)g], &cmp[(size_t)g]);
+        rcs[(size_t)g] = rc;
+        if (rc != MI32_OK) errs[(size_t)g] = g_last_error;  // thread-local: carried to the caller's thread below
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < ngpus; ++g) {
+        try { th.emplace_back(work, g); } catch (...) { work(g); }
+    }
+    work(0);
+    for (auto &t : th) t.join();
+    int worst = MI32_OK;
+    double t_tot = 0.0, t_cmp = 0.0;
+    for (int g = 0; g < ngpus; ++g) {
+        const int rc = rcs[(size_t)g];
+        if (rc == MI32_BAD_SHAPE) return MI32_BAD_SHAPE;
+        if (rc > worst) { worst = rc; if (!errs[(size_t)g].empty()) g_last_error = errs[(size_t)g]; }
+        if (tot[(size_t)g] > t_tot) t_tot = tot[(size_t)g];
+        if (cmp[(size_t)g] > t_cmp) t_cmp = cmp[(size_t)g];
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_host_call_mu);
+        g_last_total = t_tot;
+        g_last_compute = t_cmp;
+        print_reference_timing_lines();
     }
     return worst;
 }
@@ -940,9 +1040,11 @@ static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double 
     const size_t elems = (size_t)n * n;
     rc = ensure_io(h, 2 * elems, 1);  // doubles: two 4-byte units each
     if (rc != MI32_OK) return rc;
+    ProfilingGuard prof_guard;  // profiling is switched off again on every way out
     if (times10) {
         rc = mi32_set_profiling(h, 1);
         if (rc != MI32_OK) return rc;
+        prof_guard.h = h;
         double ms0[KC_COUNT]; long long cnt0[KC_COUNT];
         (void)mi32_get_profile(h, ms0, cnt0, KC_COUNT);  // drop what an earlier call left
     }
@@ -961,7 +1063,7 @@ static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double 
         inv_rowmajor = static_cast<double *>(late_out(late_ctx));
         if (!inv_rowmajor) { (void)hipStreamSynchronize(h->stream); return MI32_RUNTIME_ERROR; }
     } else {
-        parallel_page_touch(inv_rowmajor, elems * sizeof(double));
+        parallel_populate(inv_rowmajor, elems * sizeof(double));
     }
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t2 = std::chrono::steady_clock::now();
@@ -976,7 +1078,6 @@ static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double 
     if (times10) {
         double ms[KC_COUNT]; long long cnt[KC_COUNT];
         rc = mi32_get_profile(h, ms, cnt, KC_COUNT);
-        (void)mi32_set_profiling(h, 0);
         if (rc != MI32_OK) return rc;
         fill_times10(times10, ms, tq0, t0, t1, t2, t3);
     }
@@ -1038,8 +1139,8 @@ std::vector<float> matrix_inv_32(std::vector<float> matrix_vector, int matrix_or
                                       Ctx *x = static_cast<Ctx *>(c);
                                       try {
                                           x->v->reserve(x->n);  // pages first (several threads), then the value-initialisation
-                                          parallel_first_touch(x->v->data(), x->n * sizeof(float));
-                                          x->v->assign(x->n, 0.0f);
+                                          parallel_populate(x->v->data(), x->n * sizeof(float));
+                                          x->v->resize(x->n);
                                       } catch (...) { return nullptr; }
                                       return x->v->data();
                                   }, &ctx);
@@ -1134,8 +1235,8 @@ std::vector<double> matrix_inversion_FP64(std::vector<double> matrix_vector, int
                                       Ctx *x = static_cast<Ctx *>(c);
                                       try {
                                           x->v->reserve(x->n);
-                                          parallel_first_touch(x->v->data(), x->n * sizeof(double));
-                                          x->v->assign(x->n, 0.0);
+                                          parallel_populate(x->v->data(), x->n * sizeof(double));
+                                          x->v->resize(x->n);
                                       } catch (...) { return nullptr; }
                                       return x->v->data();
                                   }, &ctx);

@@ -61,6 +61,16 @@ int mi32_matrix_inv_32(const float *a_rowmajor, size_t a_len, int n, float *inv_
  * NULL, else receives one mi32_status per matrix.  Returns the worst status. */
 int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int *status);
 
+/* The same batch over ngpus GPUs of this node (ngpus <= 0: every visible device) -- what replaces the reference's
+ * platforms[0] / devices[0] (Matlab/mat_inv_32/mat_inv_32/mat_inv_32.cpp:239-244) for the callers the reference has
+ * (C++ and MATLAB: no launcher, no Python).  One context and one host thread per GPU; GPU g owns the matrices
+ * [g * ceil(batch / ngpus), min(batch, (g + 1) * ceil(batch / ngpus))), copies ITS OWN shard host -> device, inverts it
+ * and copies it back.  No data-path exchange between the GPUs (independent matrices); the return value is the worst
+ * status, status[] (may be NULL) one word per matrix.  Every matrix's inverse is bit-identical to what
+ * mi32_matrix_inv_32_batched gives for it alone.  ngpus > visible devices is MI32_BAD_SHAPE unless
+ * MI32_MULTI_OVERSUBSCRIBE=1 maps logical GPU g onto device g % visible (tests, single-GPU hosts). */
+int mi32_matrix_inv_32_batched_multi(const float *a, int n, int batch, float *inv, int *status, int ngpus);
+
 /* ---- context ------------------------------------------------------------- */
 int mi32_create(mi32_handle_t *out, int device /* HIP ordinal, <0 = current */);
 int mi32_destroy(mi32_handle_t h);
@@ -72,7 +82,7 @@ int mi32_set_algo(mi32_handle_t h, int algo);
 /* tuning knobs of the blocked path: sub-panel width (4/8/16/32, capped by what fits in registers) and the outer
  * block width (multiple of the sub-panel width, <= 512); 0 keeps the default */
 int mi32_set_blocking(mi32_handle_t h, int panel_width, int block_width);
-/* look-ahead of the blocked path (second stream; on by default for single matrices of N >= 4096) */
+/* look-ahead of the blocked path (second stream; on by default for single matrices of 3072 padded rows and more) */
 int mi32_set_lookahead(mi32_handle_t h, int enable);
 /* bytes of device workspace a call of this shape needs (excluding in/out) */
 size_t mi32_workspace_bytes(int n, int batch, int algo);

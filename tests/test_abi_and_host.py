@@ -77,11 +77,19 @@ def test_dropin_header_matches_reference_declaration():
     assert 'extern "C"' not in hdr
 
 
-def test_code_object_is_gfx950_only():
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH],
-                         capture_output=True, text=True).stdout
+def test_code_object_is_gfx950_only(tmp_path):
+    # llvm-objdump --offloading extracts the code objects NEXT TO its input: run it on a copy in a scratch
+    # directory, not inside gpu_matrix_inversion_amd/lib/ (which travels to the GPU box)
+    import shutil
+
+    copy = tmp_path / os.path.basename(_lib.LIB_PATH)
+    shutil.copy(_lib.LIB_PATH, copy)
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", str(copy)],
+                         capture_output=True, text=True, cwd=tmp_path).stdout
     archs = set(re.findall(r"gfx[0-9a-f]+", out))
     assert archs == {"gfx950"}, archs
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    assert not [f for f in os.listdir(libdir) if ".hipv4-" in f or ".host-" in f], "extracted code objects left in lib/"
 
 
 def test_shape_guards_need_no_gpu():
@@ -108,8 +116,9 @@ def test_workspace_sizes():
     # two working copies of the N x N matrix (the reference holds two N x 2N panels + N x N)
     assert 2 * n * n * 4 <= sweep < 2 * n * n * 4 + (1 << 20)
     # rows padded by 256 B, + five compact panels (32 x N), two multiplier panels (32 x 2N) and ten maps, + per block
-    # (256 pivots): the transposed multipliers, two pivot-row strips and two multiplier matrices (256 x N each)
-    assert 2 * n * n * 4 <= blocked < 2 * n * (n + 64) * 4 + 5 * 256 * n * 4 + (5 << 20)
+    # (256 pivots) eight 256 x N arrays: the transposed multipliers, 2 x (u rows, pivot rows after their sub-panel,
+    # multiplier matrix) double-buffered for the look-ahead, the parked rows of a split strip launch
+    assert 2 * n * n * 4 <= blocked < 2 * n * (n + 64) * 4 + 8 * 256 * n * 4 + (5 << 20)
     assert lib.mi32_workspace_bytes(0, 1, 0) == 0
     # padding to a multiple of 128 in the blocked path
     assert lib.mi32_workspace_bytes(1000, 1, _lib.ALGO_BLOCKED) >= 2 * 1024 * 1024 * 4

@@ -601,7 +601,7 @@ def test_three_workgroup_panel_8200(inv_blocked):
 
 
 def test_shared_panel_lost_partner_is_flagged_and_poisoned(inv_blocked):
-    """The time-out path of the shared panels.  MI32_DEBUG_DROP_PANEL_GROUP=1 (host side only) never launches
+    """The time-out path of the shared panels.  mi32_debug_drop_panel_group(1) (host side only) never launches
     the last workgroup of a shared panel -- what a foreign kernel holding the CUs would cause.  The present
     workgroup must give the partner up after a bounded wait, flag the matrix MI32_RUNTIME_ERROR, every later
     launch must skip it, and the caller must get NaN, not numbers.  The next call is healthy again."""
@@ -609,11 +609,12 @@ def test_shared_panel_lost_partner_is_flagged_and_poisoned(inv_blocked):
     a = gate_matrix(n, 40_000)
     inv = g.Inverter(algo="blocked")
     try:
-        os.environ["MI32_DEBUG_DROP_PANEL_GROUP"] = "1"
+        lib = _lib.load()
+        lib.mi32_debug_drop_panel_group(1)
         try:
             x, st = run(inv, a)
         finally:
-            del os.environ["MI32_DEBUG_DROP_PANEL_GROUP"]
+            lib.mi32_debug_drop_panel_group(0)
         assert st[0] == _lib.MI32_RUNTIME_ERROR
         assert np.isnan(x).all()
         x2, st2 = run(inv, a)
@@ -622,6 +623,85 @@ def test_shared_panel_lost_partner_is_flagged_and_poisoned(inv_blocked):
         assert float(inv.residual(ta, tx)[0, 0]) < 1e-3
     finally:
         inv.close()
+
+
+def test_two_inverters_on_two_threads_never_give_a_wrong_finite_answer(oracle):
+    """Two contexts inverting N = 4200 on one device at the same time: both use shared (two-workgroup) panels and
+    the look-ahead, and compete for the CUs those need.  Each result must be either the oracle's bits with status 0
+    or a clean MI32_RUNTIME_ERROR with a NaN-filled inverse (a panel gave a partner up) -- never finite wrong numbers."""
+    import threading
+
+    n = 4200
+    mats = [gate_matrix(n, 41_000 + i) for i in range(2)]
+    want = [oracle_inverse(oracle, m, n) for m in mats]
+    results = [None, None]
+
+    def worker(i):
+        inv = g.Inverter(algo="auto")
+        try:
+            s = torch.cuda.Stream()
+            outs = []
+            with torch.cuda.stream(s):
+                ta = torch.from_numpy(mats[i]).cuda()
+                for _ in range(3):
+                    x, st = inv.inv(ta)
+                    s.synchronize()
+                    outs.append((x.cpu().numpy(), int(st[0])))
+            results[i] = outs
+        finally:
+            inv.close()
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(2):
+        assert results[i] is not None
+        for x, st in results[i]:
+            if st == 0:
+                assert np.array_equal(x.reshape(-1), want[i]), i
+            else:
+                assert st == _lib.MI32_RUNTIME_ERROR and np.isnan(x).all(), (i, st)
+
+
+def test_multi_gpu_host_batch_entry_point_oversubscribed(oracle):
+    """mi32_matrix_inv_32_batched_multi (the C ABI's multi-GPU host batch: one context and host thread per GPU, every
+    GPU copies and inverts its own contiguous shard, worst status returned).  On this one-GPU box the logical GPUs
+    are mapped onto device 0 (MI32_MULTI_OVERSUBSCRIBE=1): the threading, the ragged shards (7 matrices over 3 and
+    over 4 GPUs), a singular member and the status reduction run as on a node; every inverse must be bit-identical
+    to the single-context result and to the oracle."""
+    n, B = 300, 7
+    mats = np.stack([gate_matrix(n, 88_000 + b) for b in range(B)])
+    mats[4] = 1.0  # singular member, lands in the middle shard
+    single, st_single = g.matrix_inv_32_batched(mats)
+    assert list(st_single) == [0, 0, 0, 0, 2, 0, 0]
+    lib = _lib.load()
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+    # more GPUs than visible without the switch: refused
+    out = np.empty_like(mats)
+    st = np.empty(B, np.int32)
+    assert lib.mi32_matrix_inv_32_batched_multi(mats.ctypes.data_as(fp), n, B, out.ctypes.data_as(fp), st.ctypes.data_as(ip),
+                                                torch.cuda.device_count() + 1) == _lib.MI32_BAD_SHAPE
+    os.environ["MI32_MULTI_OVERSUBSCRIBE"] = "1"
+    try:
+        for ngpus in (1, 2, 3, 4, 7, 9):
+            out, st = g.matrix_inv_32_batched(mats, ngpus=ngpus)
+            assert list(st) == [0, 0, 0, 0, 2, 0, 0], ngpus
+            ok = [b for b in range(B) if b != 4]
+            assert np.array_equal(out[ok], single[ok]), ngpus
+        for b in (0, 3, 6):
+            assert np.array_equal(out[b].reshape(-1), oracle.matrix_inv_32_inplace(mats[b], n))
+        # worst status is the return value; status may be NULL
+        rc = lib.mi32_matrix_inv_32_batched_multi(mats.ctypes.data_as(fp), n, B, out.ctypes.data_as(fp), None, 3)
+        assert rc == _lib.MI32_SINGULAR
+        total, compute = g.last_timing()
+        assert total >= compute > 0
+    finally:
+        del os.environ["MI32_MULTI_OVERSUBSCRIBE"]
+    # all visible devices (ngpus = 0), no switch
+    out0, st0 = g.matrix_inv_32_batched(mats, ngpus=0)
+    assert list(st0) == [0, 0, 0, 0, 2, 0, 0] and np.array_equal(out0[[0, 6]], single[[0, 6]])
 
 
 def test_sweep_2048_bit_identical_to_oracle(oracle, inv_sweep):
