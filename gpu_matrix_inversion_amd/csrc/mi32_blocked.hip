@@ -1406,11 +1406,11 @@ __device__ __forceinline__ void ostrip_body(const SubpanelArgs &A, int tile, uns
 
 // ---- one launch per sub-panel: panel(s) || update(s-1) || strip(s-1) ------------------------------
 template <int NT, int RPT, int W, bool FUSED>
-constexpr size_t subpanel_lds_bytes()
+constexpr size_t subpanel_lds_bytes(bool with_strip_tiles = true)
 {
     const size_t pb = panel_shared_bytes<NT / 64, W>() + (size_t)2 * RPT * NT * sizeof(int);
     const size_t ub = FUSED ? sizeof(UpdateTileShared<W>) * (NT / 256) : 0;
-    const size_t ob = sizeof(OStripShared<W>) * (NT / 256);
+    const size_t ob = with_strip_tiles ? sizeof(OStripShared<W>) * (NT / 256) : 0;  // (they cost the update tiles occupancy)
     const size_t m = pb > ub ? pb : ub;
     return m > ob ? m : ob;
 }
@@ -1483,10 +1483,11 @@ constexpr size_t block_strip_lds_bytes(int kb)
 {
     return ((size_t)G * (CT + 4) + (size_t)G * (kb + 4) + (size_t)2 * G * (CT + 4)) * sizeof(float) + (size_t)kb * sizeof(int);
 }
-static constexpr int kStripThreads = 1024;  // 16 waves: one 32 x 32 tile of the pivot rows each (kb 256, CT 64)
-static constexpr int kStripTPW = 1;         // tiles per wave: kb <= 256 runs CT = 64 (<= 16 tiles), wider blocks CT = 32 (<= 16 tiles)
-template <int CT, int G>
-__global__ __launch_bounds__(kStripThreads) void gj_block_strip_kernel(const float *__restrict__ src_all, size_t mstride, int np, int ld,
+// kb <= 256 runs CT = 64, wider blocks CT = 32: at most 16 tiles of 32 x 32.  SNT threads: 1024 (16 waves, one tile
+// each: a single matrix, where the launch is a chain of rounds on few workgroups) or 512 (8 waves, two tiles each:
+// GPU-filling batches -- a round is latency, so two of these per CU, 4 waves per SIMD either way, do twice the tiles).
+template <int CT, int G, int SNT>
+__global__ __launch_bounds__(SNT, 4) void gj_block_strip_kernel(const float *__restrict__ src_all, size_t mstride, int np, int ld,
                                                               const float *__restrict__ mf_all, size_t mfstride, int mf_ld,
                                                               float *__restrict__ ub_all, float *__restrict__ xs_all,
                                                               float *__restrict__ xst_all, size_t ubstride, int C0, int kb,
@@ -1496,7 +1497,8 @@ __global__ __launch_bounds__(kStripThreads) void gj_block_strip_kernel(const flo
 {
     extern __shared__ __attribute__((aligned(16))) float bs_smem[];
     constexpr int LDX = CT + 4;
-    constexpr int NT = kStripThreads;
+    constexpr int NT = SNT;
+    constexpr int kStripTPW = 16 / (SNT / 64);  // tiles per wave
     constexpr int CTT = CT / 32;  // tiles per row of tiles
     const int LT = kb + 4;
     float *s_x = bs_smem;                  // [G][LDX]   the rows of the current group
@@ -1540,7 +1542,7 @@ __global__ __launch_bounds__(kStripThreads) void gj_block_strip_kernel(const flo
     }
     // the multipliers of G steps, all kb pivot rows: requested one round ahead (registers), so that a round is the
     // strip and the update, not a dependent global round trip on top
-    constexpr int NL = (kMaxBW * (G / 4) + NT - 1) / NT;
+    constexpr int NL = ((CT == 64 ? 256 : kMaxBW) * (G / 4) + NT - 1) / NT;
     float4 lreg[NL];
     auto load_l = [&](int s0) {
 #pragma unroll
@@ -1872,7 +1874,8 @@ static hipError_t launch_subpanel(const SubpanelArgs &A, int nwgs, hipStream_t s
         });
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((gj_subpanel_kernel<NT, RPT, W, FUSED>), dim3(nwgs), dim3(NT), lds, stream, A);
+    const size_t lds_now = subpanel_lds_bytes<NT, RPT, W, FUSED>(A.os_on != 0);
+    hipLaunchKernelGGL((gj_subpanel_kernel<NT, RPT, W, FUSED>), dim3(nwgs), dim3(NT), lds_now, stream, A);
     return hipSuccess;
 }
 
@@ -1902,8 +1905,9 @@ static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelA
         // mi32_debug_drop_panel_group(1) (tests only, host side only): the last panel workgroup of the grid is never
         // launched, i.e. one panel loses a partner -- what a foreign kernel holding the CUs would cause
         A.drop_groups = g_debug_drop_panel_group.load(std::memory_order_relaxed) ? 1 : 0;
+        const size_t lds_now = A.os_on ? lds : subpanel_lds_bytes<1024, 4, 16, false>(false);
         hipLaunchKernelGGL((gj_panel_multi_kernel<16>), dim3(A.batch * A.ngroups - A.drop_groups + (os_tiles + 3) / 4),
-                           dim3(1024), lds, stream, A);
+                           dim3(1024), lds_now, stream, A);
         return hipSuccess;
     }
     const bool fused = A.upd_on != 0;
@@ -1944,7 +1948,7 @@ static hipError_t dispatch_subpanel(const BlockedPlan &p, int w, const SubpanelA
     return hipErrorInvalidValue;
 }
 
-template <int CT, int G>
+template <int CT, int G, int SNT>
 static hipError_t launch_block_strip_t(dim3 grid, size_t lds, hipStream_t st, const float *src, size_t mstride, int np, int ld,
                                        const float *mf, size_t mfstride, int mf_ld, float *ub, float *xs, float *xst,
                                        size_t ubstride, int C0, int kb, const int *map, int col_lo, int col_hi, int inside,
@@ -1955,11 +1959,11 @@ static hipError_t launch_block_strip_t(dim3 grid, size_t lds, hipStream_t st, co
     (void)hipGetDevice(&dev);
     hipError_t e = hipSuccess;
     std::call_once(once[dev & 63], [&] {
-        e = hipFuncSetAttribute((const void *)gj_block_strip_kernel<CT, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute((const void *)gj_block_strip_kernel<CT, G, SNT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)block_strip_lds_bytes<CT, G>(CT == 64 ? 256 : kMaxBW));
     });
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((gj_block_strip_kernel<CT, G>), grid, dim3(kStripThreads), lds, st, src, mstride, np, ld, mf, mfstride,
+    hipLaunchKernelGGL((gj_block_strip_kernel<CT, G, SNT>), grid, dim3(SNT), lds, st, src, mstride, np, ld, mf, mfstride,
                        mf_ld, ub, xs, xst, ubstride, C0, kb, map, col_lo, col_hi, inside, g_lo, g_hi, guard);
     return hipSuccess;
 }
@@ -1971,12 +1975,21 @@ static hipError_t launch_block_strip(int w, int batch, hipStream_t st, const flo
                                      int g_lo, int g_hi, const int *guard)
 {
 #define MI32_STRIP_CASE(GG)                                                                                               \
+    if (w == GG && batch * (np / 64) > 512) {  /* GPU-filling: small workgroups */                                        \
+        if (kb <= 256)                                                                                                    \
+            return launch_block_strip_t<64, GG, 512>(dim3(np / 64, batch), block_strip_lds_bytes<64, GG>(kb), st, src, mstride, \
+                                                     np, ld, mf, mfstride, mf_ld, ub, xs, xst, ubstride, C0, kb, map, col_lo, \
+                                                     col_hi, inside, g_lo, g_hi, guard);                                  \
+        return launch_block_strip_t<32, GG, 512>(dim3(np / 32, batch), block_strip_lds_bytes<32, GG>(kb), st, src, mstride, np, \
+                                                 ld, mf, mfstride, mf_ld, ub, xs, xst, ubstride, C0, kb, map, col_lo, col_hi, \
+                                                 inside, g_lo, g_hi, guard);                                              \
+    }                                                                                                                     \
     if (w == GG) {                                                                                                        \
         if (kb <= 256)                                                                                                    \
-            return launch_block_strip_t<64, GG>(dim3(np / 64, batch), block_strip_lds_bytes<64, GG>(kb), st, src, mstride, np, \
+            return launch_block_strip_t<64, GG, 1024>(dim3(np / 64, batch), block_strip_lds_bytes<64, GG>(kb), st, src, mstride, np, \
                                                 ld, mf, mfstride, mf_ld, ub, xs, xst, ubstride, C0, kb, map, col_lo, col_hi, \
                                                 inside, g_lo, g_hi, guard);                                               \
-        return launch_block_strip_t<32, GG>(dim3(np / 32, batch), block_strip_lds_bytes<32, GG>(kb), st, src, mstride, np, ld, \
+        return launch_block_strip_t<32, GG, 1024>(dim3(np / 32, batch), block_strip_lds_bytes<32, GG>(kb), st, src, mstride, np, ld, \
                                             mf, mfstride, mf_ld, ub, xs, xst, ubstride, C0, kb, map, col_lo, col_hi, inside, \
                                             g_lo, g_hi, guard);                                                           \
     }

@@ -3,7 +3,7 @@
 #   tools/quick_bench.sh [c2]
 set -o pipefail
 python tools/exact_debug.py 300 2300 3200 || exit 1
-python bench.py --no-cpu-baseline --no-distribute > gpurun_out/qb_c1.json 2> gpurun_out/qb_c1.err || { tail -5 gpurun_out/qb_c1.err; exit 1; }
+python bench.py --no-cpu-baseline --no-distribute --no-e2e --no-resident-batch > gpurun_out/qb_c1.json 2> gpurun_out/qb_c1.err || { tail -5 gpurun_out/qb_c1.err; exit 1; }
 python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/qb_c1.json").read().strip().splitlines()[-1])
@@ -12,7 +12,7 @@ for k, v in d["kernel_breakdown"].items():
     print("  %-18s %8.3f ms  %5.0f launches  %8.2f us" % (k, v["ms_per_step"], v["launches_per_step"], v["avg_us"]))
 PY
 if [ "$1" = "c2" ]; then
-python bench.py --n 2048 --batch 64 --no-cpu-baseline --no-distribute > gpurun_out/qb_c2.json 2> gpurun_out/qb_c2.err || { tail -5 gpurun_out/qb_c2.err; exit 1; }
+python bench.py --n 2048 --batch 64 --no-cpu-baseline --no-distribute --no-e2e > gpurun_out/qb_c2.json 2> gpurun_out/qb_c2.err || { tail -5 gpurun_out/qb_c2.err; exit 1; }
 python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/qb_c2.json").read().strip().splitlines()[-1])

@@ -7,7 +7,7 @@ OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/prof
 mkdir -p "$OUT"
 cd "${GRAFT_REPO_ROOT:-$PWD}" || exit 1
 rocprofv3 --kernel-trace --stats -d "$OUT/$NAME" -o "$NAME" --output-format csv -- python3 bench.py --steps 5 --warmup 2 \
-    --no-cpu-baseline --no-profile-pass --no-e2e "$@" > "$OUT/${NAME}_bench.json" 2> "$OUT/$NAME.log" || { tail -5 "$OUT/$NAME.log"; exit 1; }
+    --no-cpu-baseline --no-profile-pass --no-e2e --no-resident-batch "$@" > "$OUT/${NAME}_bench.json" 2> "$OUT/$NAME.log" || { tail -5 "$OUT/$NAME.log"; exit 1; }
 python3 - "$OUT/$NAME" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
