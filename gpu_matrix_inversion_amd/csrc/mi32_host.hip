@@ -775,7 +775,7 @@ static void fill_times10(double *times10, const double *ms, std::chrono::steady_
 // vector's reserved storage before it is value-initialised and (b) on the caller's output buffer while the device
 // works -- which therefore keeps its contents until the copy back (mat_inv_32_c.h: "written only on MI32_OK /
 // MI32_SINGULAR").  Where the kernel does not know the advice the pages are faulted by the copy itself, as before.
-static void parallel_populate(void *p, size_t bytes)
+static void parallel_populate(void *p, size_t bytes, bool may_rewrite = false)
 {
     const size_t kPage = 4096, kMin = (size_t)8 << 20;
     if (bytes < kMin) return;
@@ -786,12 +786,20 @@ static void parallel_populate(void *p, size_t bytes)
     nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
     const size_t span = hi - lo;
     const size_t chunk = ((span / nt) + kPage - 1) & ~(kPage - 1);
-    auto populate = [](uintptr_t a, size_t len) {
+    // may_rewrite (the caller's output buffer, ours to write for the duration of the call): where the kernel does not
+    // know the advice (Linux < 5.14) every page's first byte is read and written back unchanged instead
+    auto populate = [may_rewrite](uintptr_t a, size_t len) {
+        int rc = -1;
 #ifdef MADV_POPULATE_WRITE
-        (void)madvise(reinterpret_cast<void *>(a), len, MADV_POPULATE_WRITE);
-#else
-        (void)a; (void)len;
+        rc = madvise(reinterpret_cast<void *>(a), len, MADV_POPULATE_WRITE);
 #endif
+        if (rc != 0 && may_rewrite) {
+            for (size_t off = 0; off < len; off += 4096) {
+                volatile char *q = reinterpret_cast<volatile char *>(a + off);
+                const char v = *q;
+                *q = v;
+            }
+        }
     };
     std::vector<std::thread> th;
     for (unsigned i = 1; i < nt; ++i) {
@@ -843,7 +851,7 @@ static int host_invert_32_on(mi32_context *h, std::chrono::steady_clock::time_po
         inv = static_cast<float *>(late_out(late_ctx));
         if (!inv) { (void)hipStreamSynchronize(h->stream); return MI32_RUNTIME_ERROR; }
     } else {
-        parallel_populate(inv, floats * sizeof(float));  // the device is busy for the next milliseconds
+        parallel_populate(inv, floats * sizeof(float), true);  // the device is busy for the next milliseconds
     }
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t2 = std::chrono::steady_clock::now();
@@ -1063,7 +1071,7 @@ static int host_invert_64(const double *a_rowmajor, size_t a_len, int n, double 
         inv_rowmajor = static_cast<double *>(late_out(late_ctx));
         if (!inv_rowmajor) { (void)hipStreamSynchronize(h->stream); return MI32_RUNTIME_ERROR; }
     } else {
-        parallel_populate(inv_rowmajor, elems * sizeof(double));
+        parallel_populate(inv_rowmajor, elems * sizeof(double), true);
     }
     MI32_HIP(hipStreamSynchronize(h->stream));
     const auto t2 = std::chrono::steady_clock::now();
