@@ -218,7 +218,7 @@ class Inverter:
         _lib.check(self._lib.mi32_set_algo(self._h, self.algo), "mi32_set_algo")
         if panel_width or block_width:
             _lib.check(self._lib.mi32_set_blocking(self._h, panel_width, block_width), "mi32_set_blocking")
-        if not pivoting:  # the reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10), sweep path
+        if not pivoting:  # the reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10); fp32: blocked from 512 rows on
             _lib.check(self._lib.mi32_set_pivoting(self._h, 0), "mi32_set_pivoting")
 
     def close(self):

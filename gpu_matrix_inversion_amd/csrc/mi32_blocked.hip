@@ -778,6 +778,8 @@ struct SubpanelArgs {
     int u_c0;        // first column of sub-panel t
     int u_has_prev;  // sub-panel t itself had a pending update (t >= 1 within its block)
     int u_above_hi;  // positions below this were not in panel(t): their G_t is computed by the update tile
+    int u_panel_hi;  // ... and positions from this on neither (np with pivoting; no-pivot variant: only the W pivot rows
+                     // go through the "panel", gj_diag_panel_kernel)
     int C0, kb;      // the outer block
     const float *x;  // working copy in order after t-1
     float *y;        // working copy written in order after t
@@ -1144,7 +1146,7 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
     const float *mt = A.u_mt + (size_t)b * A.mtstride;
     const int mtld = A.mtld;
     const int *map = A.u_submap + (size_t)b * np;
-    const bool some_above = row0 < A.u_above_hi;  // some of this tile's rows were not in panel(t)
+    const bool some_above = row0 < A.u_above_hi || row0 + 64 > A.u_panel_hi;  // some of this tile's rows were not in panel(t)
 
     // Two dependent rounds of global loads in all: the maps first, then everything they index (old values,
     // multipliers, pivot rows) -- requested into registers back to back, before the first of them is needed.
@@ -1204,7 +1206,7 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
 #pragma unroll
         for (int j = 0; j < CPT; ++j) { v[j] = 0.0f; fm[j] = 0.0f; }
         float *mfrow = A.u_mf + (size_t)b * A.mfstride + (size_t)T.s_rs[rr] * A.mf_ld + (c0 - A.C0);
-        if (grow >= A.u_above_hi) {
+        if (grow >= A.u_above_hi && grow < A.u_panel_hi) {
 #pragma unroll
             for (int j = 0; j < CPT; ++j) fm[j] = mt[(size_t)(q4 * CPT + j) * mtld + T.s_map[rr]];
             if (tx == 0) {
@@ -1402,6 +1404,74 @@ __device__ __forceinline__ void ostrip_body(const SubpanelArgs &A, int tile, uns
                 *reinterpret_cast<const float4 *>(&T.s_xs[kk * LDU + c4]);
         }
     }
+}
+
+// ---- the no-pivot variant's "panel" (matrix_inversion_no_pivots.cpp:10: findCrr / fixRow / fixColumn, no search,
+//      no swap): the W x W diagonal block alone ------------------------------------------------------------------
+// Without a pivot search the W pivot rows of a sub-panel are known in advance -- rows c0 .. c0+W-1 -- and what every
+// OTHER row does in the W steps depends on those rows only: it is the update tiles that take each of them through the
+// steps (above_rows_step, with the normalised pivot rows this kernel exports), thousands of rows in parallel on the
+// whole chip instead of one workgroup.  This kernel runs the W steps on the W x W block of the pivot rows themselves
+// (one thread per entry, two LDS hand-overs per step) and leaves what the panel kernel leaves for its rows: their new
+// entries (gt), their multipliers (mt; own step: the pivot), the normalised pivot rows (aux) and the status.
+// Workgroups past the matrices are strip(t) tiles, as in the other panel launches.
+template <int W>
+__global__ __launch_bounds__(256) void gj_diag_panel_kernel(SubpanelArgs A)
+{
+    constexpr size_t kBytes = sizeof(OStripShared<W>) > (3 * W * W + 2 * W) * sizeof(float) ? sizeof(OStripShared<W>)
+                                                                                          : (3 * W * W + 2 * W) * sizeof(float);
+    __shared__ __attribute__((aligned(16))) unsigned char dp_smem[kBytes];
+    if ((int)blockIdx.x >= A.batch) {
+        ostrip_body<W>(A, (int)blockIdx.x - A.batch, dp_smem, threadIdx.x);
+        return;
+    }
+    float *s_d = reinterpret_cast<float *>(dp_smem);  // [W][W] the block
+    float *s_prn = s_d + W * W;                       // [W][W] normalised pivot rows
+    float *s_mt = s_prn + W * W;                      // [W][W] multipliers [step][row]
+    const int b = blockIdx.x, tid = threadIdx.x, np = A.np, c0 = A.c0;
+    if (matrix_given_up(A.guard, b)) return;
+    const float *pt = A.pt_in + (size_t)b * A.tstride;
+    for (int i = tid; i < W * W; i += 256) s_d[i] = pt[(size_t)(i % W) * np + c0 + i / W];  // s_d[row][col]
+    __syncthreads();
+    bool singular = false;
+    for (int m = 0; m < W; ++m) {
+        const float piv = s_d[m * W + m];
+        if (piv == 0.0f || piv - piv != 0.0f) singular = true;
+        // fixRow (IEEE division); the identity column's entry 1 becomes 1/piv
+        for (int c = tid; c < W; c += 256) s_prn[m * W + c] = (c == m ? 1.0f : s_d[m * W + c]) / piv;
+        __syncthreads();
+        // fixColumn on the other W-1 rows of the block; the pivot column holds the implicit identity column (0)
+        constexpr int EPT = (W * W + 255) / 256;
+        float vv[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = tid + q * 256;
+            vv[q] = 0.0f;
+            if (i < W * W) {
+                const int k = i / W, c = i % W;
+                const float f = s_d[k * W + m];
+                if (k == m) vv[q] = s_prn[m * W + c];
+                else vv[q] = __builtin_fmaf(-f, s_prn[m * W + c], (c == m) ? 0.0f : s_d[i]);
+                if (c == 0) s_mt[m * W + k] = f;  // own step: the pivot itself
+            }
+        }
+        __syncthreads();  // every thread has read column m of its rows before anyone overwrites it
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = tid + q * 256;
+            if (i < W * W) s_d[i] = vv[q];
+        }
+        __syncthreads();
+    }
+    float *gt = A.gt_out + (size_t)b * A.tstride;
+    float *mt = A.mt_out + (size_t)b * A.mtstride;
+    float *aux = A.aux_out + (size_t)b * kAuxFloats;
+    for (int i = tid; i < W * W; i += 256) {
+        gt[(size_t)(i % W) * np + c0 + i / W] = s_d[i];               // gt[col][row]
+        mt[(size_t)(i / W) * A.mtld + c0 + i % W] = s_mt[i];           // mt[step][row]
+        aux[i] = s_prn[i];
+    }
+    if (singular && tid == 0 && A.status) atomicMax(&A.status[b], (int)MI32_SINGULAR);
 }
 
 // ---- one launch per sub-panel: panel(s) || update(s-1) || strip(s-1) ------------------------------
@@ -2025,7 +2095,8 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
         // the first two sub-panels of the first block are exported as they are: the first has no pending
         // update at all, the second gets the first one's update in its panel's prologue
         ProfScope ps(prof, KC_INIT, stream);
-        const PanelExport ex0 = {ws.pt[0], ws.pt_bstride, 0, p.wblk[0], np <= fused_rows ? 2 : 1};
+        const PanelExport ex0 = {ws.pt[0], ws.pt_bstride, 0, ex.pivoting ? (int)p.wblk[0] : 16,
+                                 (ex.pivoting && np <= fused_rows) ? 2 : 1};
         hipLaunchKernelGGL(blocked_init_kernel, dim3((np + 255) / 256, (np + 15) / 16, batch), dim3(256), 0, stream,
                            d_a, p.n, np, p.ld, ws.mstride, ws.m0, ex0, ws.tstride, ws.orig, d_status);
     }
@@ -2056,7 +2127,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
         });
     }
     // plans with shared panels: every launch skips a matrix whose panel lost a partner (SubpanelArgs::guard)
-    const int *guard = p.multi_panel ? d_status : nullptr;
+    const int *guard = (p.multi_panel && ex.pivoting) ? d_status : nullptr;
     unsigned panel_launches = 0;  // tags of the multi-workgroup panels' exchange granules: unique per launch
     if (p.multi_panel) {  // no stale tag of an earlier call may match
         if ((e = hipMemsetAsync(ws.xch, 0, (size_t)kXchGranules * sizeof(unsigned long long) * batch, stream)) != hipSuccess)
@@ -2074,14 +2145,16 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
         const int kb = (C0 + p.bw <= np) ? p.bw : np - C0;
         int **rsb = &ws.rowsrc[2 * (blk & 1)];
         float *mf = ws.mf[blk & 1], *ub = ws.ub[blk & 1], *xs = ws.xs[blk & 1];
-        const int w = p.wblk[blk];                                       // sub-panel width of this block
-        const int w_next = (blk + 1 < p.nblk) ? p.wblk[blk + 1] : w;     // ... and of the next one
+        // sub-panel width of this block and of the next one (the no-pivot variant has no register-resident panel
+        // whose rows would limit it)
+        const int w = ex.pivoting ? (int)p.wblk[blk] : 16;
+        const int w_next = !ex.pivoting ? 16 : (blk + 1 < p.nblk) ? (int)p.wblk[blk + 1] : w;
         const int S = kb / w;                                            // sub-panels of this block (even)
         // Fused mode: launch s = panel(s) || update(s-1), the panel applies update(s-1) to its own columns in a
         // prologue.  It pays while the panel workgroup holds at most 2 rows per lane (measured: 2048^2 3.23 ->
         // 3.06 ms, 1024^2 1.40 -> 1.27 ms); with more rows the prologue (rows x W x W fmaf on ONE CU) costs what
         // the update launch did (4096^2: 8.9 -> 9.5 ms), so those blocks keep panel(s) and update(s) apart.
-        const bool fused = (np - C0) <= fused_rows;
+        const bool fused = ex.pivoting && (np - C0) <= fused_rows;
         // The strip(t) tiles follow the block sub-panel by sub-panel in the columns outside it -- unless the look-ahead
         // is on: those columns are then still being written by the previous block's second-stream update while this
         // block's panels run (the next block's columns too: half (A) of the previous block covered THIS block's), and
@@ -2114,6 +2187,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 P.invsub_prev = ws.invsub[(s + 1) & 1];
                 P.submap_out = ws.submap[s & 1];
                 P.invsub_out = ws.invsub[s & 1];
+                if (!ex.pivoting) P.ngroups = 1;
                 P.rowsrc_in = rsb[fused ? (s + 1) & 1 : 0];
                 P.rowsrc_out = rsb[fused ? s & 1 : 0];
                 P.rowsrc_alt = (fused && s == 0) ? rsb[1] : nullptr;
@@ -2131,13 +2205,14 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                 U.u_c0 = C0 + t * w;
                 U.u_has_prev = fused && (t > 0);
                 U.u_above_hi = U.u_has_prev ? U.u_c0 - w : U.u_c0;  // = the first row panel(t) held
+                U.u_panel_hi = ex.pivoting ? np : U.u_c0 + w;
                 U.C0 = C0; U.kb = kb;
                 U.x = x; U.y = y;
                 U.u_gt = ws.gt[t & 1];
                 U.u_mt = ws.mt[t & 1];
-                U.u_rowsrc = rsb[fused ? t & 1 : 0];
+                U.u_rowsrc = ex.pivoting ? rsb[fused ? t & 1 : 0] : ws.orig;  // no pivoting: no row ever moves
                 U.u_mf = mf;
-                U.u_submap = ws.submap[t & 1];
+                U.u_submap = ex.pivoting ? ws.submap[t & 1] : ws.orig;
                 U.u_pt_in = ws.pt[t % 3];
                 U.u_aux = ws.aux[t & 1];
                 // fused: sub-panel t+2's columns (t+1's are brought up to date by its own panel);
@@ -2159,6 +2234,7 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
             if (fused) {
                 SubpanelArgs A = P;  // one launch: panel(s) || update(s-1) || strip(s-1)
                 A.upd_on = U.upd_on; A.u_c0 = U.u_c0; A.u_has_prev = U.u_has_prev; A.u_above_hi = U.u_above_hi;
+                A.u_panel_hi = U.u_panel_hi;
                 A.C0 = U.C0; A.kb = U.kb; A.x = U.x; A.y = U.y; A.u_gt = U.u_gt; A.u_submap = U.u_submap;
                 A.u_mt = U.u_mt; A.u_rowsrc = U.u_rowsrc; A.u_mf = U.u_mf;
                 A.u_pt_in = U.u_pt_in; A.u_aux = U.u_aux; A.u_exp = U.u_exp;
@@ -2170,7 +2246,12 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
                     ProfScope ps(prof, KC_UPDATE_IN, stream);
                     if ((e = dispatch_subpanel(p, w, U, stream)) != hipSuccess) return e;
                 }
-                if (P.panel_on) {
+                if (P.panel_on && !ex.pivoting) {
+                    // the no-pivot variant: the W x W diagonal block alone (+ the strip tiles that ride with a panel)
+                    ProfScope ps(prof, KC_PANEL, stream);
+                    const int os_tiles = P.os_on ? batch * P.os_ntiles : 0;
+                    hipLaunchKernelGGL((gj_diag_panel_kernel<16>), dim3(batch + os_tiles), dim3(256), 0, stream, P);
+                } else if (P.panel_on) {
                     ProfScope ps(prof, KC_PANEL, stream);
                     if ((e = dispatch_subpanel(p, w, P, stream)) != hipSuccess) return e;
                 }
@@ -2182,10 +2263,12 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
             const int next = C0 + kb;  // first column of the next block
             const bool has_next = next < np;
             const int kb_next = has_next ? ((next + p.bw <= np) ? p.bw : np - next) : 0;
-            const int *rowsrc = rsb[fused ? (S - 1) & 1 : 0];  // position after the block -> row index at its start
+            // position after the block -> row index at its start
+            const int *rowsrc = ex.pivoting ? rsb[fused ? (S - 1) & 1 : 0] : ws.orig;
             // the next block's first two sub-panels, fully updated, for its first two panels
             const PanelExport exn =
-                has_next ? PanelExport{ws.pt[0], ws.pt_bstride, next, w_next, (np - next) <= fused_rows ? 2 : 1} : no_export;
+                has_next ? PanelExport{ws.pt[0], ws.pt_bstride, next, w_next, (ex.pivoting && (np - next) <= fused_rows) ? 2 : 1}
+                         : no_export;
             const int copy = (x != oth) ? 1 : 0;
             if (pending_b) {  // this update reads all of `cur` and overwrites `oth`: the previous (B) must be done
                 if ((e = hipStreamWaitEvent(stream, ex.events[ev], 0)) != hipSuccess) return e;

@@ -299,10 +299,11 @@ static void lookahead_geometry(int cus, int n, int *workgroups, bool *exclusive)
 
 static int resolve_algo(const mi32_context *h, int n)
 {
-    if (h && !h->pivoting) return MI32_ALGO_SWEEP;  // the no-pivot variant exists on the sweep path only
     int algo = h ? h->algo : MI32_ALGO_AUTO;
     if (algo == MI32_ALGO_AUTO) algo = env_int("MI32_ALGO", MI32_ALGO_AUTO);
-    if (algo != MI32_ALGO_SWEEP && algo != MI32_ALGO_BLOCKED) algo = (n >= 32) ? MI32_ALGO_BLOCKED : MI32_ALGO_SWEEP;  // measured cross-over on MI355X
+    // the no-pivot variant (fp32): blocked from 512 rows on (the W x W diagonal block is its whole "panel")
+    const int cross = (h && !h->pivoting) ? 512 : 32;
+    if (algo != MI32_ALGO_SWEEP && algo != MI32_ALGO_BLOCKED) algo = (n >= cross) ? MI32_ALGO_BLOCKED : MI32_ALGO_SWEEP;  // measured cross-over on MI355X
     if (algo == MI32_ALGO_BLOCKED && !blocked_supported(n)) algo = MI32_ALGO_SWEEP;  // panel would not fit in registers
     return algo;
 }
@@ -577,6 +578,7 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
         ex.n_events = h->aux_stream ? 8 : 0;
         lookahead_geometry(h->cu_count, n, &ex.aux_workgroups, &ex.aux_exclusive);
         ex.prof = h->prof;
+        ex.pivoting = h->pivoting;
         const BlockedPlan p = plan_blocked(h, n, batch);
         if (!split_batch(h, algo, n, batch)) {
             e = blocked_invert(p, d_a, d_inv, batch, d_status, h->ws, ex);

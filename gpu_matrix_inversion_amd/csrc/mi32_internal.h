@@ -124,6 +124,7 @@ struct BlockedExec {
     int aux_workgroups = 0;  // grid of the persistent look-ahead kernel: CUs minus the ones kept free
     bool aux_exclusive = false;  // its workgroups take a whole CU's LDS: nothing of the main stream shares their CUs
     Profiler *prof = nullptr;
+    bool pivoting = true;  // false: the reference's no-pivot variant (the diagonal entry is every step's pivot)
 };
 hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, int batch, int *d_status, void *ws,
                           const BlockedExec &ex);

