@@ -384,7 +384,7 @@ static int ensure_ws(mi32_context *h, size_t bytes)
 
 extern "C" {
 
-int mi32_version(void) { return 110; }
+int mi32_version(void) { return 120; }
 const char *mi32_last_error(void) { return g_last_error.c_str(); }
 
 int mi32_create(mi32_handle_t *out, int device)

@@ -1,22 +1,19 @@
-// mi32_rank_bw.h -- the rank-bw update of the blocked path, second generation (gfx950 only).
+// mi32_rank_bw.h -- the rank-bw update of the blocked path (gfx950 only).
 //
-//   dst[i][j] = (i in [c0,c0+kdim) ? 0 : src[map[i]][j]) + sum_k G[i][k] * src[map[c0+k]][j]
+//   dst[i][j] = C[i][j] - sum_m f_m[i] * u_m[j],   m = 0 .. kdim-1 ascending, one fmaf chain per element
 //
-// i.e. fixColumnKernel (/root/reference/Matlab/mat_inv_32/mat_inv_32/mat_inv_32.cpp:13-57) for all
-// columns outside the current block of kdim pivots, with the block's kdim eliminations applied at once
-// on the fp32 matrix cores.  Same arithmetic as gj_rank_bw_update_kernel in mi32_blocked.hip (one
-// k-ascending v_mfma_f32_32x32x2_f32 chain per output element from zero, old value added last), so the
-// results are bit-identical; what changes is how the operands reach the matrix pipe:
+// i.e. fixColumnKernel (/root/reference/Matlab/mat_inv_32/mat_inv_32/mat_inv_32.cpp:13-57) for all columns outside
+// the current block of kdim pivots, with the block's kdim eliminations applied at once on the fp32 matrix cores, in
+// the reference's own order: f_m[i] = the entry row i had in the pivot column when step m ran (the block's
+// multipliers), u_m[j] = the pivot row of step m as fixColumn saw it (the block's strip, mi32_blocked.hip), C = the
+// element's old value -- a v_mfma_f32_32x32x2_f32 chain with C as its accumulator is exactly that fmaf chain.
 //
 //  * both operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no
 //    ds_write instructions, and the loads of k-tile t+1 are in flight during the MFMAs of k-tile t;
-//  * for that the A operand (the block's panel G, np x kdim, row-major in the working copy) is first
-//    transposed into a compact k-major array Gk[k][row] by gj_panel_transpose_kernel, so that an A tile
-//    is [BK][128] contiguous rows exactly like a B tile -- the LDS image of an LDS-DMA is lane-linear,
-//    it cannot transpose;
-//  * the row map of the kdim pivot rows (the B operand's row gather) is read ONCE into LDS; the first
-//    kernel fetched map[c0+k] from global memory inside every k-tile, a dependent L2 round trip in
-//    front of every B load that all co-resident workgroups hit in lock-step.
+//  * for that the A operand (the negated multipliers, row-major by block-start row in mf) is first gathered through
+//    the block's row map and transposed into a compact k-major array Gk[k][row] by gj_mult_transpose_kernel, so that
+//    an A tile is [BK][128] contiguous rows exactly like a B tile -- the LDS image of an LDS-DMA is lane-linear, it
+//    cannot transpose; the B operand ub[k][col] is compact and k-major as the strip leaves it.
 #pragma once
 #include "mi32_internal.h"
 #include <type_traits>
@@ -56,33 +53,6 @@ __device__ __forceinline__ void panel_export_store4(const PanelExport &e, size_t
 typedef float rb_float16v __attribute__((ext_vector_type(16)));
 typedef float rb_f4v __attribute__((ext_vector_type(4)));
 
-// Gk[k][row] = g[row][c0 + k], k < kdim: 64 x 64 tiles through LDS, both global sides coalesced.
-__global__ __launch_bounds__(256) void gj_panel_transpose_kernel(const float *__restrict__ g_all, size_t gstride, int np,
-                                                                  int ld, int c0, float *__restrict__ gk_all,
-                                                                  size_t gkstride)
-{
-    __shared__ float t[64][65];
-    const int b = blockIdx.z;
-    const int row0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-    const int tid = threadIdx.x;
-    const float *g = g_all + (size_t)b * gstride;
-    float *gk = gk_all + (size_t)b * gkstride;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = (tid >> 4) + 16 * q, c4 = (tid & 15) * 4;
-        const rb_f4v v = *reinterpret_cast<const rb_f4v *>(g + (size_t)(row0 + r) * ld + c0 + k0 + c4);
-        t[r][c4] = v[0]; t[r][c4 + 1] = v[1]; t[r][c4 + 2] = v[2]; t[r][c4 + 3] = v[3];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = (tid >> 4) + 16 * q, r4 = (tid & 15) * 4;
-        rb_f4v v;
-        v[0] = t[r4][k]; v[1] = t[r4 + 1][k]; v[2] = t[r4 + 2][k]; v[3] = t[r4 + 3][k];
-        *reinterpret_cast<rb_f4v *>(gk + (size_t)(k0 + k) * np + row0 + r4) = v;
-    }
-}
-
 // One LDS-DMA: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at a wave-uniform base.
 __device__ __forceinline__ void rb_glds16(const float *gsrc, float *lds_wave_base)
 {
@@ -112,7 +82,7 @@ __device__ __forceinline__ void rb_tile_of(int id, int TR, int TC, int &rt, int 
     }
 }
 
-// Diagnostic builds (tools/rank_bw_bench.hip, -DMI32_RB_STAMPS) record s_memtime at the phase boundaries of
+// Diagnostic builds (-DMI32_RB_STAMPS) record s_memtime at the phase boundaries of
 // every workgroup; in the product build the macro expands to nothing.
 #ifdef MI32_RB_STAMPS
 __device__ unsigned long long *g_rb_stamps;  // [workgroup][8]
@@ -124,20 +94,6 @@ __device__ unsigned long long *g_rb_stamps;  // [workgroup][8]
 #else
 #define MI32_RB_STAMP(slot_) do { } while (0)
 #endif
-
-// The peeled tail of the k-loop with the old values' prefetch: k-tile pf0 + i issues chunk i (i < NCH) and every
-// k-tile that follows one lets that chunk stay in flight; the last two k-tiles issue nothing.
-template <int NCH, typename F, int... Is>
-__device__ __forceinline__ void rank_bw2_tail_impl(F &k_tile, int pf0, std::integer_sequence<int, Is...>)
-{
-    (k_tile(pf0 + Is, std::integral_constant<bool, (Is >= 1 && Is <= NCH)>{},
-            std::integral_constant<int, (Is < NCH ? Is : -1)>{}), ...);
-}
-template <int NCH, typename F>
-__device__ __forceinline__ void rank_bw2_tail(F &k_tile, int pf0)
-{
-    rank_bw2_tail_impl<NCH>(k_tile, pf0, std::make_integer_sequence<int, NCH + 2>{});
-}
 
 // One 128 x BN output tile (rt, ct) of matrix b (BN = 128 or 64: 4 waves as 2 x 2, 64 x BN/2 each).
 // rb_smem: rank_bw2_lds_bytes<BK, BN>(kdim) bytes of LDS.
