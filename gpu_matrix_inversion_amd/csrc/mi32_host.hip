@@ -318,9 +318,9 @@ static BlockedPlan plan_blocked(const mi32_context *h, int n, int batch)
         // 23.0 ms vs 24.7 ms; single 4096^2: 11.4 ms vs 11.2 ms).
         const double elems = (double)batch * (double)n * (double)n;
         bw = (batch >= 8 && elems >= 64.0 * 1024.0 * 1024.0) ? 128 : 256;
-        // the largest matrices spend most of their time in the rank-bw update, which runs at 120 instead of 114
-        // TFLOP/s with a 512-deep k-loop (measured 16384^2: 122 -> 112 ms; 12288^2: 58 vs 62 ms the other way)
-        if (batch == 1 && n > 14336) bw = 512;
+        // (Rounds 1-2 ran N > 14336 with bw = 512 for the rank-bw update's sake: 120 instead of 114 TFLOP/s.  With the
+        // pivot-row strips of round 3 an in-block update tile costs more and there are twice as many per sub-panel at
+        // 512: 16384^2 122 ms at 256, 126 at 384, 140 at 512; 12288^2 65.5 vs 75.9; 8192^2 33.9 vs 38.0.)
     }
     return make_blocked_plan(n, w, bw, batch);
 }
