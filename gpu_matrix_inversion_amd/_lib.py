@@ -31,6 +31,7 @@ C_ABI_SYMBOLS = (
     "mi32_matrix_inv_32",
     "mi32_matrix_inv_32_batched",
     "mi32_matrix_inv_32_batched_multi",
+    "mi32_shard_range",
     "mi32_create",
     "mi32_destroy",
     "mi32_set_stream",
@@ -112,6 +113,8 @@ def load() -> ctypes.CDLL:
     lib.mi32_matrix_inv_32.argtypes = [fp, ctypes.c_size_t, ctypes.c_int, fp]
     lib.mi32_matrix_inv_32_batched.restype = ctypes.c_int
     lib.mi32_matrix_inv_32_batched.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ip]
+    lib.mi32_shard_range.restype = ctypes.c_int
+    lib.mi32_shard_range.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ip]
     lib.mi32_debug_drop_panel_group.restype = ctypes.c_int
     lib.mi32_debug_drop_panel_group.argtypes = [ctypes.c_int]
     lib.mi32_matrix_inv_32_batched_multi.restype = ctypes.c_int

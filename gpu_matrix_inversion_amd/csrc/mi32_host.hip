@@ -922,6 +922,17 @@ std::mutex g_multi_mu;                 // guards the table
 std::vector<MultiSlot *> g_multi;      // logical GPU -> slot (never shrinks; slots are never freed)
 }  // namespace
 
+// GPU g of G owns the matrices [g * ceil(B / G), min(B, (g + 1) * ceil(B / G))) (possibly none)
+extern "C" int mi32_shard_range(int batch, int ngpus, int g, int *lo, int *hi)
+{
+    if (batch < 0 || ngpus <= 0 || g < 0 || g >= ngpus || !lo || !hi) return MI32_BAD_SHAPE;
+    const int per = (batch + ngpus - 1) / ngpus;
+    const long long l = (long long)g * per;
+    *lo = l < batch ? (int)l : batch;
+    *hi = (l + per < batch) ? (int)(l + per) : batch;
+    return MI32_OK;
+}
+
 extern "C" int mi32_matrix_inv_32_batched_multi(const float *a, int n, int batch, float *inv, int *status, int ngpus)
 {
     if (!a || !inv || n <= 0 || batch <= 0) return MI32_BAD_SHAPE;
@@ -939,7 +950,6 @@ extern "C" int mi32_matrix_inv_32_batched_multi(const float *a, int n, int batch
         return MI32_BAD_SHAPE;
     }
     if (ngpus > batch) ngpus = batch;  // at least one matrix per GPU
-    const int per = (batch + ngpus - 1) / ngpus;  // ceil(B / G) matrices per GPU
     std::vector<MultiSlot *> slots((size_t)ngpus, nullptr);
     {
         std::lock_guard<std::mutex> lk(g_multi_mu);
@@ -954,7 +964,8 @@ extern "C" int mi32_matrix_inv_32_batched_multi(const float *a, int n, int batch
     std::vector<double> tot((size_t)ngpus, 0.0), cmp((size_t)ngpus, 0.0);
     const size_t mat = (size_t)n * n;
     auto work = [&](int g) {
-        const int lo = g * per, hi = (lo + per < batch) ? lo + per : batch;
+        int lo = 0, hi = 0;
+        (void)mi32_shard_range(batch, ngpus, g, &lo, &hi);
         if (lo >= hi) return;  // ragged tail: this GPU has nothing
         MultiSlot *sl = slots[(size_t)g];
         std::lock_guard<std::mutex> lk(sl->mu);

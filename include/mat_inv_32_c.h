@@ -70,6 +70,8 @@ int mi32_matrix_inv_32_batched(const float *a, int n, int batch, float *inv, int
  * mi32_matrix_inv_32_batched gives for it alone.  ngpus > visible devices is MI32_BAD_SHAPE unless
  * MI32_MULTI_OVERSUBSCRIBE=1 maps logical GPU g onto device g % visible (tests, single-GPU hosts). */
 int mi32_matrix_inv_32_batched_multi(const float *a, int n, int batch, float *inv, int *status, int ngpus);
+/* the shard of GPU g of ngpus: [*lo, *hi) (empty for the GPUs a ragged batch leaves without work); needs no device */
+int mi32_shard_range(int batch, int ngpus, int g, int *lo, int *hi);
 
 /* ---- context ------------------------------------------------------------- */
 int mi32_create(mi32_handle_t *out, int device /* HIP ordinal, <0 = current */);

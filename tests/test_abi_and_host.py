@@ -108,6 +108,31 @@ def test_shape_guards_need_no_gpu():
     assert g.matrix_inv_64(np.ones(6), 2).size == 0 and g.matrix_inv_64(np.ones(4), -1).size == 0
 
 
+def test_c_abi_shard_range_equals_the_python_sharding():
+    """mi32_matrix_inv_32_batched_multi partitions a host batch with mi32_shard_range: the same contiguous ceil-sized
+    ranges as sharding.shard_range, ragged and empty shards included; every matrix in exactly one shard."""
+    from gpu_matrix_inversion_amd.sharding import shard_range
+
+    lib = _lib.load()
+    lo, hi = ctypes.c_int(-1), ctypes.c_int(-1)
+    for batch in (0, 1, 7, 8, 64, 512, 513):
+        for ngpus in (1, 2, 3, 4, 8, 9):
+            covered = []
+            for g_ in range(ngpus):
+                assert lib.mi32_shard_range(batch, ngpus, g_, ctypes.byref(lo), ctypes.byref(hi)) == _lib.MI32_OK
+                assert (lo.value, hi.value) == shard_range(batch, ngpus, g_), (batch, ngpus, g_)
+                covered += list(range(lo.value, hi.value))
+            assert covered == list(range(batch))
+    assert lib.mi32_shard_range(8, 0, 0, ctypes.byref(lo), ctypes.byref(hi)) == _lib.MI32_BAD_SHAPE
+    assert lib.mi32_shard_range(8, 2, 2, ctypes.byref(lo), ctypes.byref(hi)) == _lib.MI32_BAD_SHAPE
+    # the multi-GPU host batch answers its shape guards before it touches a device
+    fp = ctypes.POINTER(ctypes.c_float)
+    buf = (ctypes.c_float * 4)()
+    assert lib.mi32_matrix_inv_32_batched_multi(ctypes.cast(buf, fp), 0, 1, ctypes.cast(buf, fp), None, 1) == _lib.MI32_BAD_SHAPE
+    assert lib.mi32_matrix_inv_32_batched_multi(ctypes.cast(buf, fp), 2, 0, ctypes.cast(buf, fp), None, 1) == _lib.MI32_BAD_SHAPE
+    assert lib.mi32_matrix_inv_32_batched_multi(None, 2, 1, ctypes.cast(buf, fp), None, 1) == _lib.MI32_BAD_SHAPE
+
+
 def test_workspace_sizes():
     lib = _lib.load()
     n = 4096
