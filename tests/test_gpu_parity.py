@@ -704,6 +704,31 @@ def test_multi_gpu_host_batch_entry_point_oversubscribed(oracle):
     assert list(st0) == [0, 0, 0, 0, 2, 0, 0] and np.array_equal(out0[[0, 6]], single[[0, 6]])
 
 
+@pytest.mark.parametrize("n", [300, 1300, 3200])
+def test_blocked_scaled_inputs_take_the_full_division_and_stay_bit_identical(oracle, inv_blocked, n):
+    """The pivot-row strips divide through a shortened form of hipcc's own division when both operands lie in
+    [2^-47, 2^48) and through the full expansion otherwise (mi32_blocked.hip, strip_div).  Matrices scaled by 2^-56 /
+    2^+56 put every strip on the full expansion (tiny pivots / tiny numerators), a mixed one -- half the rows scaled
+    -- takes both branches inside one strip; each must still be the oracle's bits, and a power-of-two scaling must
+    carry through exactly: inv(2^k A) == 2^-k inv(A)."""
+    a = gate_matrix(n, 66_000 + n)
+    base, st = run(inv_blocked, a)
+    assert st[0] == 0
+    for k in (-56, 56):
+        sc = np.float32(2.0) ** k
+        got, st = run(inv_blocked, a * sc)
+        assert st[0] == 0
+        assert np.array_equal(got, base / sc), k
+        if n <= 1300:
+            assert np.array_equal(got.reshape(-1), oracle_inverse(oracle, a * sc, n)), k
+    mixed = a.copy()
+    mixed[::2] *= np.float32(2.0) ** -52   # every other row tiny: pivots and numerators on both sides of the range
+    got, st = run(inv_blocked, mixed)
+    want, info = oracle_inverse(oracle, mixed, n, return_info=True)
+    assert st[0] == info["status"] == 0
+    assert np.array_equal(got.reshape(-1), want)
+
+
 def test_sweep_2048_bit_identical_to_oracle(oracle, inv_sweep):
     n = 2048
     a = gate_matrix(n, 20_000)
