@@ -2083,7 +2083,12 @@ hipError_t blocked_invert(const BlockedPlan &p, const float *d_a, float *d_inv, 
     // look-ahead pays when the GPU is otherwise idle during the panel phase: a single large matrix
     // (measured in round 1: 8192^2 51 -> 45 ms, 16384^2 399 -> 330 ms, 4096^2 11.2 -> 11.0 ms, 2048^2 4.2 -> 4.4 ms; with
     // the half on CUs of its own, round 2: 3584^2 7.39 -> 7.00 ms, 3072^2 5.79 -> 5.63, 2560^2 4.32 -> 4.34, 2048^2 3.01 -> 3.14)
-    const bool lookahead = ex.aux != nullptr && ex.n_events >= 4 && ex.aux_workgroups > 0 && batch == 1 && np >= 3072;
+    // Round 3 (reference-order arithmetic: the pivot rows' strip per block sits between the block's last panel and its
+    // rank-bw update, and rides in the panel launches only WITHOUT the second stream), with / without:
+    // 4096^2 10.23 / 10.09, 4352^2 11.50 / 11.66, 5120^2 15.02 / 15.79, 8192^2 34.0 / 37.1 -> on above 4096 padded rows.
+    int la_min = 4096 + 1;
+    if (const char *ev = std::getenv("MI32_LOOKAHEAD_MIN")) la_min = std::atoi(ev) > 2048 ? std::atoi(ev) : 2048;
+    const bool lookahead = ex.aux != nullptr && ex.n_events >= 4 && ex.aux_workgroups > 0 && batch == 1 && np >= la_min;
     hipError_t e;
     int fused_rows = 2048;  // see "Fused mode" below; fused instances exist for at most 2048 rows
     if (const char *ev = std::getenv("MI32_FUSED_ROWS")) fused_rows = std::atoi(ev) < 2048 ? std::atoi(ev) : 2048;

@@ -84,7 +84,7 @@ int mi32_set_algo(mi32_handle_t h, int algo);
 /* tuning knobs of the blocked path: sub-panel width (4/8/16/32, capped by what fits in registers) and the outer
  * block width (multiple of the sub-panel width, <= 512); 0 keeps the default */
 int mi32_set_blocking(mi32_handle_t h, int panel_width, int block_width);
-/* look-ahead of the blocked path (second stream; on by default for single matrices of 3072 padded rows and more) */
+/* look-ahead of the blocked path (second stream; on by default for single matrices of more than 4096 padded rows) */
 int mi32_set_lookahead(mi32_handle_t h, int enable);
 /* bytes of device workspace a call of this shape needs (excluding in/out) */
 size_t mi32_workspace_bytes(int n, int batch, int algo);

@@ -460,14 +460,15 @@ def test_blocked_2300_unfused_then_fused_blocks_bit_identical_to_oracle(oracle, 
 
 
 def _default_inverter():
-    return g.Inverter(algo="auto")   # what matrix_inv_32 runs: AUTO plan, look-ahead on
+    return g.Inverter(algo="auto")   # what matrix_inv_32 runs: AUTO plan, look-ahead where it pays
 
 
-def test_c1_4096_default_plan_bit_identical_to_oracle(oracle, inv_sweep):
+def test_c1_4096_default_plan_bit_identical_to_oracle(oracle, inv_sweep, monkeypatch):
     """BASELINE configs[1] itself: N = 4096, the default plan (bw 256, W 16; four rows per lane in the unfused
-    panels of the first half, fused launches in the second, look-ahead halves on the second stream) against the
-    reference-order oracle run live on this box -- the step-by-step restatement itself, 12 s of CPU -- against its
-    digest committed from the build container (tests/golden/make_oracle_digests.py), and against the sweep path."""
+    panels of the first half, fused launches in the second, the pivot rows' strips riding in the panel launches; one
+    stream -- the look-ahead starts above 4096 rows) against the reference-order oracle run live on this box -- the
+    step-by-step restatement itself, 12 s of CPU -- against its digest committed from the build container
+    (tests/golden/make_oracle_digests.py), against the sweep path, and with the look-ahead forced on."""
     dig = load_oracle_digest(4096)
     n, seed = 4096, int(dig["seed"])
     a = gate_matrix(n, seed)
@@ -475,7 +476,7 @@ def test_c1_4096_default_plan_bit_identical_to_oracle(oracle, inv_sweep):
     try:
         assert inv.resolved_algo(n, 1) == g.ALGO_BLOCKED
         got, st = run(inv, a)
-        inv.set_lookahead(False)          # the single-stream schedule must give the same bits
+        monkeypatch.setenv("MI32_LOOKAHEAD_MIN", "2048")   # the two-stream schedule must give the same bits
         got1, st1 = run(inv, a)
     finally:
         inv.close()
@@ -488,13 +489,16 @@ def test_c1_4096_default_plan_bit_identical_to_oracle(oracle, inv_sweep):
     check_against_oracle_digest(got, dig)
 
 
-@pytest.mark.parametrize("n", [3072, 3500, 6100])
-def test_lookahead_sizes_bit_identical_to_oracle(oracle, n):
-    """The look-ahead schedule outside 4096: its lower end (3072 padded rows on; the half runs on half of the CUs,
-    with a whole CU's LDS per workgroup), a ragged size in between, and 6100 (6144 padded rows: the first panels are
-    shared by two workgroups, the half runs on three quarters of the CUs) -- with the second stream and without it,
-    bit for bit the reference-order oracle."""
+@pytest.mark.parametrize("n", [3072, 3500, 4300, 6100])
+def test_lookahead_sizes_bit_identical_to_oracle(oracle, n, monkeypatch):
+    """The look-ahead schedule outside 4096: forced on below its default range (MI32_LOOKAHEAD_MIN, read per call: 3072
+    padded rows -- the half runs on half of the CUs, with a whole CU's LDS per workgroup -- and a ragged size), its
+    default lower end (4300 -> 4352 padded rows) and 6100 (6144 padded rows: the first panels are shared by two
+    workgroups, the half runs on three quarters of the CUs) -- with the second stream and without it, bit for bit the
+    reference-order oracle."""
     a = gate_matrix(n, 7000 + n)
+    if n < 4097:
+        monkeypatch.setenv("MI32_LOOKAHEAD_MIN", "2048")
     inv = _default_inverter()
     try:
         got, st = run(inv, a)
