@@ -276,7 +276,12 @@ static int env_int(const char *name, int dflt)
 //   N 10240:  16/84 41.7   32/84 40.6    32/156 42.1   64/156 40.9   128/156 50.2
 //   N 12288:  16/84 58.5   32/84 57.9    32/156 59.0   64/156 60.8   128/156 84.7
 //   N 16384:  16/84 107.5  32/84 111.4   32/156 125.4  64/156 124.3  (8/84 107.0, 5/84 137.7: the shared panels starve)
-// Up to ~8192 rows the half is short against the panel phase: it gets few CUs, all to itself, and the panel chain
+// Round 3 (reference-order strips, bw = 256 everywhere), same notation:
+//   N  8192:  8/84 34.8   16/84 34.9   32/84 33.2   64/84 33.9   32/156 35.6   64/156 33.9
+//   N 12288:  8/84 70.5   16/84 70.4   32/84 66.9   64/84 67.9   32/156 72.8   64/156 68.4
+//   N 16384:  8/84 119.1  16/84 121.8  32/84 125.4  64/84 141.9  32/156 134.1
+//   (two or three look-ahead workgroups per CU, 76 / 50 KB each: 8192 37.7, 12288 77.8, 16384 143-145: the shared panels starve)
+// Up to ~7168 rows the half is short against the panel phase: it gets few CUs, all to itself, and the panel chain
 // keeps the rest undisturbed; above, every block waits for the half: it gets all but 32 / 16 CUs and shares them.
 // MI32_RESERVED_CUS / MI32_LA_EXCLUSIVE override.
 static void lookahead_geometry(int cus, int n, int *workgroups, bool *exclusive)
@@ -284,9 +289,9 @@ static void lookahead_geometry(int cus, int n, int *workgroups, bool *exclusive)
     int reserve;
     bool excl;
     if (n < 5120) { reserve = cus / 2; excl = true; }
-    else if (n <= 9216) { reserve = cus / 4; excl = true; }
+    else if (n <= 7168) { reserve = cus / 4; excl = true; }
     else if (n <= 14336) { reserve = cus / 8; excl = false; }
-    else { reserve = cus / 16; excl = false; }
+    else { reserve = cus / 32; excl = false; }
     const int r_env = env_int("MI32_RESERVED_CUS", 0);
     if (r_env > 0) reserve = r_env;
     if (reserve < 1) reserve = 1;
