@@ -346,62 +346,59 @@ __device__ __forceinline__ float lane_bcast(float v, int srclane)
 //
 // The division x / pivot (fixRow, mat_inv_32.cpp:149: IEEE, correctly rounded) is the other half of a step's
 // latency: hipcc expands it into v_div_scale x2, v_rcp, 6 fma, v_div_fmas, v_div_fixup -- 11 dependent instructions
-// of which only five depend on x once the operands need no scaling.  strip_div splits it: the pivot's part
-// (reciprocal and its Newton step: the very instructions of the expansion, on the unscaled pivot) is computed with
-// the prefetch, kStripAhead steps early; the chain keeps q0 = x r1, e1 = fma(-d, q0, x), q1 = fma(e1, r1, q0),
+// of which only five depend on x once the operands need no scaling.  The strip splits it: the pivots' part
+// (reciprocal and its Newton step: the very instructions of the expansion, on the unscaled pivot) is computed once,
+// BK pivots in BK lanes, before the chain starts; the chain keeps q0 = x r1, e1 = fma(-d, q0, x), q1 = fma(e1, r1, q0),
 // e2 = fma(-d, q1, x), q = fma(e2, r1, q1).  v_div_scale leaves both operands alone and v_div_fixup returns q as it is
 // exactly when (ISA, V_DIV_SCALE_F32 / V_DIV_FIXUP_F32) neither is zero, denormal, infinite or NaN, the exponents are
 // less than 96 apart, the numerator's biased exponent is above 23 and the denominator's below 253: the fast path is
 // taken for 2^-47 <= |.| < 2^48 on both sides -- bit for bit the full expansion's result -- and for an exact zero
-// numerator; anything else takes the expansion itself (one wave-uniform branch).
+// numerator.  Whether every operand was in range is collected beside the chain (no branch per step); if one was not,
+// the whole strip is run again from the saved rows with the expansion itself (strip_steps_full_division).
 static constexpr int kStripAhead = 3;
 __device__ __forceinline__ bool strip_div_in_range(float v)
 {
     return __builtin_fabsf(v) >= 0x1p-47f && __builtin_fabsf(v) < 0x1p48f;
 }
-// x / d, d = -dneg; r1 = the refined reciprocal of d (strip_fetch); d_ok: d is in the fast path's range.
-// An exact zero x takes the fast path too: its five instructions return a zero (of either sign: -0.0 == 0.0, and
-// nothing downstream can tell them apart but the sign of another zero).
-__device__ __forceinline__ float strip_div(float x, float dneg, float r1, bool d_ok)
-{
-    float q = x * r1;
-    float e = __builtin_fmaf(dneg, q, x);
-    q = __builtin_fmaf(e, r1, q);
-    e = __builtin_fmaf(dneg, q, x);
-    q = __builtin_fmaf(e, r1, q);
-    const bool fast = d_ok && (strip_div_in_range(x) || x == 0.0f);
-    if (!__all(fast)) {
-        const float full = x / -dneg;
-        q = fast ? q : full;
-    }
-    return q;
-}
-template <int BK, int M>
-__device__ __forceinline__ void strip_fetch(float (&nfw)[kStripAhead + 1][BK / 4], float (&pw)[kStripAhead + 1],
-                                            float (&rw)[kStripAhead + 1], const float *s_lt, int LT, int g)
+// The multipliers of step M for this lane's rows, read kStripAhead steps early (ALIGNED: one 16-byte LDS read)
+template <int BK, int M, bool ALIGNED>
+__device__ __forceinline__ void strip_fetch(float (&nfw)[kStripAhead + 1][BK / 4], const float *s_lt, int LT, int g)
 {
     constexpr int CPT = BK / 4;
     if constexpr (M < BK) {
+        if constexpr (ALIGNED && CPT == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(s_lt + M * LT + CPT * g);
+            nfw[M % (kStripAhead + 1)][0] = v.x;
+            nfw[M % (kStripAhead + 1)][1] = v.y;
+            nfw[M % (kStripAhead + 1)][2] = v.z;
+            nfw[M % (kStripAhead + 1)][3] = v.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) nfw[M % (kStripAhead + 1)][j] = s_lt[M * LT + CPT * g + j];
-        const float dneg = s_lt[M * LT + M];  // -pivot
-        const float r = __builtin_amdgcn_rcpf(-dneg);
-        const float e0 = __builtin_fmaf(dneg, r, 1.0f);
-        pw[M % (kStripAhead + 1)] = dneg;
-        rw[M % (kStripAhead + 1)] = __builtin_fmaf(e0, r, r);
+            for (int j = 0; j < CPT; ++j) nfw[M % (kStripAhead + 1)][j] = s_lt[M * LT + CPT * g + j];
+        }
     }
 }
-template <int BK, int M>
+// One step on the fast division.  dv / rv: lane m (mod BK) holds -pivot_m and the refined reciprocal of pivot_m; the
+// step's pair reaches every lane as two scalars (v_readlane: off the chain).  `ok` collects whether every numerator
+// was in the fast path's range (or an exact zero: its five instructions return a zero of either sign, -0.0 == 0.0, and
+// nothing downstream can tell them apart but the sign of another zero) -- no branch inside the chain.
+template <int BK, int M, bool ALIGNED>
 __device__ __forceinline__ void strip_step(float (&x)[BK / 4], float (&uu)[BK], float (&nfw)[kStripAhead + 1][BK / 4],
-                                           float (&pw)[kStripAhead + 1], float (&rw)[kStripAhead + 1], const float *s_lt,
-                                           int LT, int g, bool d_ok)
+                                           float dv, float rv, bool &ok, const float *s_lt, int LT, int g)
 {
     constexpr int CPT = BK / 4;
     constexpr int kQuad = (M / CPT) * 0x55;  // quad_perm:[q,q,q,q]
-    strip_fetch<BK, M + kStripAhead>(nfw, pw, rw, s_lt, LT, g);
+    strip_fetch<BK, M + kStripAhead, ALIGNED>(nfw, s_lt, LT, g);
+    const float dneg = lane_bcast(dv, M);
+    const float r1 = lane_bcast(rv, M);
     __builtin_amdgcn_sched_barrier(0);
     const float xm = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[M % CPT]), kQuad, 0xf, 0xf, false));
-    const float u = strip_div(xm, pw[M % (kStripAhead + 1)], rw[M % (kStripAhead + 1)], d_ok);
+    float q = xm * r1;
+    float e = __builtin_fmaf(dneg, q, xm);
+    q = __builtin_fmaf(e, r1, q);
+    e = __builtin_fmaf(dneg, q, xm);
+    const float u = __builtin_fmaf(e, r1, q);
+    ok = ok && (strip_div_in_range(xm) || xm == 0.0f);
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const float upd = __builtin_fmaf(nfw[M % (kStripAhead + 1)][j], u, x[j]);
@@ -410,25 +407,71 @@ __device__ __forceinline__ void strip_step(float (&x)[BK / 4], float (&uu)[BK], 
     uu[M] = u;
     __builtin_amdgcn_sched_barrier(0);
 }
-// u_m is stored at the end, by one lane of each quad: no LDS store between the steps.
-template <int BK, int... Ms>
-__device__ __forceinline__ void strip_steps(float (&x)[BK / 4], const float *s_lt, int LT, int g, float *s_u, int LDU,
-                                            std::integer_sequence<int, Ms...>)
+// The same BK steps with the compiler's own IEEE division (v_div_scale / v_div_fmas / v_div_fixup): taken when a pivot
+// or a numerator lies outside the fast path's range -- rare, and then for the whole strip.
+template <int BK>
+__device__ __forceinline__ void strip_steps_full_division(float (&x)[BK / 4], float (&uu)[BK], const float *s_lt, int LT, int g)
 {
+    constexpr int CPT = BK / 4;
+#pragma unroll 1
+    for (int m = 0; m < BK; ++m) {
+        const int src = (threadIdx.x & 60) | (m / CPT);  // the quad's lane that holds row m
+        float xm = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const float v = __shfl(x[j], src, 64);
+            xm = (j == m % CPT) ? v : xm;
+        }
+        const float u = xm / -s_lt[m * LT + m];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const float upd = __builtin_fmaf(s_lt[m * LT + CPT * g + j], u, x[j]);
+            x[j] = (j == m % CPT && g == m / CPT) ? u : upd;
+        }
+#pragma unroll
+        for (int k = 0; k < BK; ++k) uu[k] = (k == m) ? u : uu[k];
+    }
+}
+// u_m is stored at the end, by one lane of each quad: no LDS store between the steps.
+template <int BK, bool ALIGNED, int... Ms>
+__device__ __forceinline__ void strip_steps_t(float (&x)[BK / 4], const float *s_lt, int LT, int g, float *s_u, int LDU,
+                                              std::integer_sequence<int, Ms...>)
+{
+    constexpr int CPT = BK / 4;
     float uu[BK];
-    float nfw[kStripAhead + 1][BK / 4], pw[kStripAhead + 1], rw[kStripAhead + 1];
-    // all BK pivots inside the fast division's range?  (one LDS read per lane and a ballot, before the chain starts)
+    float nfw[kStripAhead + 1][BK / 4];
+    float x0[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) x0[j] = x[j];
+    // the pivots' part of the divisions, once per strip: lane m (mod BK) takes pivot m
     const int lane_m = (int)(threadIdx.x & 63) % BK;
-    const bool d_ok = __all(strip_div_in_range(s_lt[lane_m * LT + lane_m]));
-    strip_fetch<BK, 0>(nfw, pw, rw, s_lt, LT, g);
-    strip_fetch<BK, 1>(nfw, pw, rw, s_lt, LT, g);
-    strip_fetch<BK, 2>(nfw, pw, rw, s_lt, LT, g);
+    const float dv = s_lt[lane_m * LT + lane_m];  // -pivot
+    const float r = __builtin_amdgcn_rcpf(-dv);
+    const float e0 = __builtin_fmaf(dv, r, 1.0f);
+    const float rv = __builtin_fmaf(e0, r, r);
+    bool ok = strip_div_in_range(dv);
+    strip_fetch<BK, 0, ALIGNED>(nfw, s_lt, LT, g);
+    strip_fetch<BK, 1, ALIGNED>(nfw, s_lt, LT, g);
+    strip_fetch<BK, 2, ALIGNED>(nfw, s_lt, LT, g);
     static_assert(kStripAhead == 3, "the three fetches above");
-    (strip_step<BK, Ms>(x, uu, nfw, pw, rw, s_lt, LT, g, d_ok), ...);
+    (strip_step<BK, Ms, ALIGNED>(x, uu, nfw, dv, rv, ok, s_lt, LT, g), ...);
+    if (!__all(ok)) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) x[j] = x0[j];
+        strip_steps_full_division<BK>(x, uu, s_lt, LT, g);
+    }
     if (g == 0) {
 #pragma unroll
         for (int m = 0; m < BK; ++m) s_u[m * LDU] = uu[m];
     }
+}
+// Every caller keeps s_lt 16-byte aligned with LT a multiple of 4 (PanelShared::lt, UpdateTileShared::s_lt,
+// OStripShared::s_lt, the block strip kernel's s_lt + s0): a step's multipliers are one 16-byte LDS read at W = 16.
+template <int BK, int... Ms>
+__device__ __forceinline__ void strip_steps(float (&x)[BK / 4], const float *s_lt, int LT, int g, float *s_u, int LDU,
+                                            std::integer_sequence<int, Ms...> seq)
+{
+    strip_steps_t<BK, true>(x, s_lt, LT, g, s_u, LDU, seq);
 }
 
 // ---- the panel: W pivot steps on a register-resident slab ----------------------
