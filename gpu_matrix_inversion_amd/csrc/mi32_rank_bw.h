@@ -68,14 +68,34 @@ constexpr size_t rank_bw2_lds_bytes(int kdim)
     return (size_t)(2 * BK * (128 + BN)) * sizeof(float) + (size_t)(128 + kdim) * sizeof(int);
 }
 
-// XCD-aware tile order (see mi32_blocked.hip): workgroups that share an XCD cover a compact sub-grid.
-__device__ __forceinline__ void rb_tile_of(int id, int TR, int TC, int &rt, int &ct)
+// XCD-aware tile order (see mi32_blocked.hip): workgroups that share an XCD (= an L2) cover a compact sub-grid of
+// TR/2 x TC/4 tiles, and walk it in column strips of `sw` tiles, row by row inside a strip: the strip's B operand
+// (sw x 128 columns x kdim steps) stays in the XCD's 4 MB L2 while the rows go by, and every A row tile is fetched once
+// per strip.  Row-major over the whole sub-grid (rounds 1-2) re-fetched the sub-grid's B panel for every few tile rows
+// once it outgrew the L2: 16384^2, kdim 256, 1.97x the algorithmic bytes from HBM.
+__device__ __forceinline__ int rb_strip_width(int kdim, int bn)
+{
+    const int sw = (2 * 1024 * 1024) / (bn * kdim * (int)sizeof(float));  // half the L2 for the B strip
+    return sw < 1 ? 1 : sw;
+}
+__device__ __forceinline__ void rb_tile_of(int id, int TR, int TC, int sw, int &rt, int &ct)
 {
     if ((TR & 1) == 0 && (TC & 3) == 0) {
         const int xcd = id & 7, idx = id >> 3;
         const int tr = TR / 2, tc = TC / 4;
-        rt = (xcd >> 2) * tr + idx / tc;
-        ct = (xcd & 3) * tc + idx % tc;
+        int r, c;
+        const int nfull = tc / sw;  // full strips
+        if (idx < nfull * tr * sw) {
+            const int strip = idx / (tr * sw), rem = idx - strip * (tr * sw);
+            r = rem / sw;
+            c = strip * sw + rem % sw;
+        } else {  // the last, narrower strip
+            const int w = tc - nfull * sw, rem = idx - nfull * tr * sw;
+            r = rem / w;
+            c = nfull * sw + rem % w;
+        }
+        rt = (xcd >> 2) * tr + r;
+        ct = (xcd & 3) * tc + c;
     } else {
         rt = id / TC;
         ct = id % TC;
@@ -179,7 +199,9 @@ __device__ __forceinline__ void rank_bw2_tile(
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                acc[tm][tn][reg] = tile_in_block ? xs[(size_t)(row0 + lr - c0) * np + col] : src[(size_t)s_map[lr] * ld + col];
+                // old values are read once: streaming loads, so that they do not push the operand strips out of the L2
+                acc[tm][tn][reg] = tile_in_block ? xs[(size_t)(row0 + lr - c0) * np + col]
+                                                 : __builtin_nontemporal_load(src + (size_t)s_map[lr] * ld + col);
             }
         }
     MI32_RB_STAMP(1);
@@ -228,7 +250,7 @@ __device__ __forceinline__ void rank_bw2_tile(
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int grow = row0 + wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                dst[(size_t)grow * ld + col] = acc[tm][tn][reg];
+                __builtin_nontemporal_store(acc[tm][tn][reg], dst + (size_t)grow * ld + col);
             }
             // the next block's first sub-panels, compact and transposed: registers 4q .. 4q+3 are 4 consecutive rows
 #pragma unroll
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(256, WPS) void gj_rank_bw2_kernel(
     extern __shared__ __attribute__((aligned(16))) float rb_smem[];
     if (guard != nullptr && __builtin_amdgcn_readfirstlane(guard[blockIdx.y]) == MI32_RUNTIME_ERROR) return;  // given up
     int rt, ct;
-    rb_tile_of(blockIdx.x, np / 128, np / BN, rt, ct);
+    rb_tile_of(blockIdx.x, np / 128, np / BN, rb_strip_width(kdim, BN), rt, ct);
     rank_bw2_tile<BK, BN, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, ub_all, xs_all, np, ld, mstride, c0, kdim,
                               map_all, copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
 }
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void gj_rank_bw2_persistent_kernel(
     const int T = np / 128;
     for (int id = blockIdx.x; id < T * T; id += gridDim.x) {
         int rt, ct;
-        rb_tile_of(id, T, T, rt, ct);
+        rb_tile_of(id, T, T, rb_strip_width(kdim, 128), rt, ct);
         rank_bw2_tile<BK, 128, PF>(src_all, dst_all, g_all, gstride, gk_all, gkstride, ub_all, xs_all, np, ld, mstride, c0,
                                    kdim, map_all, copy_panel, ex, tstride, skip_lo, skip_hi, blockIdx.y, rt, ct, rb_smem);
         __syncthreads();  // the next tile re-uses the LDS buffers and maps

@@ -22,7 +22,7 @@ CONFIGS = {
     "c1": ("blocked_n4096_b1_bw256", "gj_rank_bw2_kernel", 8.0 * 4096 * (4096 - 256) + 8.0 * 4096 * 256),
     "c2": ("blocked_n2048_b64_bw128", "gj_rank_bw2_kernel", 64 * (8.0 * 2048 * (2048 - 128) + 8.0 * 2048 * 128)),
     "sweep": ("sweep_n4096_b1", "gj_sweep_step_kernel", 8.0 * 4096 * 4097),
-    "c4": ("blocked_n16384_b1_bw512", "gj_rank_bw2_kernel", 8.0 * 16384 * (16384 - 512) + 8.0 * 16384 * 512),
+    "c4": ("blocked_n16384_b1_bw256", "gj_rank_bw2_kernel", 8.0 * 16384 * (16384 - 256) + 8.0 * 16384 * 256),
 }
 table = {}
 for name, (key, kern, alg) in CONFIGS.items():
