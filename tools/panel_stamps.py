@@ -63,6 +63,7 @@ def main():
               f"total {total:.0f}")
         print(f"  load {d(0, 1):.0f}  prologue {d(1, 2):.0f}  steps sum {sum(steps):.0f} (per step med {np.median(steps):.0f}, "
               f"min {min(steps):.0f}, max {max(steps):.0f})  post-steps sync {d(3 + w - 1, 48):.0f}  epilogue {d(48, 49):.0f}")
+        print("  steps: " + " ".join(f"{v:.0f}" for v in steps))
         r = w // 2
         names = ["search", "dpp-max", "ballot+cand-write", "cand-readback", "divide", "publish", "barrier", "key-read",
                  "prn-read", "fma", "labels+winner"]
