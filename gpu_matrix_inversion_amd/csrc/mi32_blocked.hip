@@ -1655,7 +1655,7 @@ __global__ __launch_bounds__(SNT, 4) void gj_block_strip_kernel(const float *__r
     }
     // the multipliers of G steps, all kb pivot rows: requested one round ahead (registers), so that a round is the
     // strip and the update, not a dependent global round trip on top
-    constexpr int NL = ((CT == 64 ? 256 : kMaxBW) * (G / 4) + NT - 1) / NT;
+    constexpr int NL = ((CT == 128 ? 128 : CT == 64 ? 256 : kMaxBW) * (G / 4) + NT - 1) / NT;
     float4 lreg[NL];
     auto load_l = [&](int s0) {
 #pragma unroll
@@ -2073,7 +2073,7 @@ static hipError_t launch_block_strip_t(dim3 grid, size_t lds, hipStream_t st, co
     hipError_t e = hipSuccess;
     std::call_once(once[dev & 63], [&] {
         e = hipFuncSetAttribute((const void *)gj_block_strip_kernel<CT, G, SNT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)block_strip_lds_bytes<CT, G>(CT == 64 ? 256 : kMaxBW));
+                                (int)block_strip_lds_bytes<CT, G>(CT == 128 ? 128 : CT == 64 ? 256 : kMaxBW));
     });
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((gj_block_strip_kernel<CT, G, SNT>), grid, dim3(SNT), lds, st, src, mstride, np, ld, mf, mfstride,
@@ -2089,6 +2089,10 @@ static hipError_t launch_block_strip(int w, int batch, hipStream_t st, const flo
 {
 #define MI32_STRIP_CASE(GG)                                                                                               \
     if (w == GG && batch * (np / 64) > 512) {  /* GPU-filling: small workgroups */                                        \
+        if (kb <= 128 && C0 % 128 == 0 && np % 128 == 0)  /* 128 columns: the strip uses all 512 threads */               \
+            return launch_block_strip_t<128, GG, 512>(dim3(np / 128, batch), block_strip_lds_bytes<128, GG>(kb), st, src, mstride, \
+                                                      np, ld, mf, mfstride, mf_ld, ub, xs, xst, ubstride, C0, kb, map, col_lo, \
+                                                      col_hi, inside, g_lo, g_hi, guard);                                 \
         if (kb <= 256)                                                                                                    \
             return launch_block_strip_t<64, GG, 512>(dim3(np / 64, batch), block_strip_lds_bytes<64, GG>(kb), st, src, mstride, \
                                                      np, ld, mf, mfstride, mf_ld, ub, xs, xst, ubstride, C0, kb, map, col_lo, \
