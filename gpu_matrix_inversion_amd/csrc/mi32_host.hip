@@ -554,11 +554,12 @@ int mi32_reserve(mi32_handle_t h, int n, int batch)
 
 // A GPU-filling batch of the blocked path is run as two halves on the context's two streams: the MFMA-bound
 // rank-bw launches of one half overlap the latency / HBM-bound sub-panel launches of the other (64 x 2048^2:
-// 18.5 -> 17.4 ms; three or four parts lose).  Both halves use the blocking of the whole batch, so a matrix's
+// 18.5 -> 17.4 ms; three or four parts lose; round 3: 8 x 4096^2 23.6 -> 22.1 ms, 4 x 4096^2 15.7 -> 15.0: from four
+// matrices on).  Both halves use the blocking of the whole batch, so a matrix's
 // result does not depend on the split; mi32_set_lookahead(h, 0) turns the second stream off altogether.
 static bool split_batch(const mi32_context *h, int algo, int n, int batch)
 {
-    return algo == MI32_ALGO_BLOCKED && h->lookahead && h->split_stream != nullptr && batch >= 16 &&
+    return algo == MI32_ALGO_BLOCKED && h->lookahead && h->split_stream != nullptr && batch >= env_int("MI32_BATCH_SPLIT_MIN", 4) &&
            (double)batch * n * n >= 64.0 * 1024.0 * 1024.0 && env_int("MI32_BATCH_SPLIT", 1) != 0;
 }
 
@@ -585,7 +586,9 @@ int mi32_inv_device(mi32_handle_t h, const float *d_a, int n, int batch, float *
         ex.prof = h->prof;
         ex.pivoting = h->pivoting;
         const BlockedPlan p = plan_blocked(h, n, batch);
-        if (!split_batch(h, algo, n, batch)) {
+        // (plans with panels shared by several workgroups are not split: those workgroups need whole CUs at the same
+        // time, which the other half's rank-bw grid would keep from them for the length of its launch)
+        if (!split_batch(h, algo, n, batch) || p.multi_panel) {
             e = blocked_invert(p, d_a, d_inv, batch, d_status, h->ws, ex);
         } else {
             const int b0 = (batch + 1) / 2, b1 = batch - b0;
