@@ -767,9 +767,10 @@ def test_c2_subset_8_of_2048(inv_blocked):
     print("8 x 2048^2 (bw 256, unsplit) residual", r)
 
 
-def test_split_batch_is_bit_identical_to_the_unsplit_batch(inv_blocked):
+def test_split_batch_is_bit_identical_to_the_unsplit_batch(oracle, inv_blocked):
     """A GPU-filling batch runs as two halves on two streams (both with the blocking of the whole batch): every
-    matrix's inverse and status must be exactly what the single-stream run gives, odd batch sizes included."""
+    matrix's inverse and status must be exactly what the single-stream run gives, odd batch sizes included -- and the
+    reference-order oracle's bits (this shape runs the 128-column block strip kernel of bw = 128 batches)."""
     n, B = 1024, 67   # 67 x 1024^2 elements >= 64 Mi: split into 34 + 33
     mats = torch.from_numpy(np.stack([gate_matrix(n, 80_000 + b) for b in range(B)])).cuda()
     mats[5] = 1.0     # one singular member, in the first half
@@ -789,6 +790,31 @@ def test_split_batch_is_bit_identical_to_the_unsplit_batch(inv_blocked):
     assert torch.equal(x_split[ok], x_one[ok])
     r = inv_blocked.residual(mats[ok], x_split[ok])
     assert float(r[:, 0].max()) < 1e-3
+    for b in (0, 33, 34, 66):
+        want_b = oracle_inverse(oracle, gate_matrix(n, 80_000 + b), n)
+        assert np.array_equal(x_split[b].cpu().numpy().reshape(-1), want_b), b
+
+
+def test_small_resident_batch_is_split_and_bit_identical(oracle, inv_blocked):
+    """Five matrices of 3700 rows (>= 64 Mi elements: split 3 + 2 over the two streams; unfused four-rows-per-lane
+    panels in the first blocks, whose launches leave most of the chip to the other half): the same bits as the
+    single-stream run and as the reference-order oracle."""
+    n, B = 3700, 5
+    mats_np = [dist_matrix("ref100" if b % 2 else "gate", n, 81_000 + b) for b in range(B)]
+    mats = torch.from_numpy(np.stack(mats_np)).cuda()
+    x_split, st_split = inv_blocked.inv(mats)
+    torch.cuda.synchronize()
+    os.environ["MI32_BATCH_SPLIT"] = "0"
+    try:
+        x_one, st_one = inv_blocked.inv(mats)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["MI32_BATCH_SPLIT"]
+    assert st_split.tolist() == [0] * B and st_one.tolist() == [0] * B
+    assert torch.equal(x_split, x_one)
+    for b in (1, 4):
+        want_b = oracle_inverse(oracle, mats_np[b], n)
+        assert np.array_equal(x_split[b].cpu().numpy().reshape(-1), want_b), b
 
 
 def test_c4_single_16384_maximum_size(inv_blocked):
