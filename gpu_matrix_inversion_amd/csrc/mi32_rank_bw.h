@@ -191,19 +191,45 @@ __device__ __forceinline__ void rank_bw2_tile(
     const int lhalf = lane >> 5;
     const int nk = kdim / BK;
     rb_float16v acc[2][TN];
+    if (tile_in_block) {
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = col0 + wc * (BN / 2) + tn * 32 + lcol;
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = col0 + wc * (BN / 2) + tn * 32 + lcol;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                // old values are read once: streaming loads, so that they do not push the operand strips out of the L2
-                acc[tm][tn][reg] = tile_in_block ? xs[(size_t)(row0 + lr - c0) * np + col]
-                                                 : __builtin_nontemporal_load(src + (size_t)s_map[lr] * ld + col);
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int lr = wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                    acc[tm][tn][reg] = xs[(size_t)(row0 + lr - c0) * np + col];
+                }
+            }
+    } else {
+        // Old values through the row map: read once -> streaming loads (they must not push the operand strips out of
+        // the L2).  Straight-line code: the 16 map entries of a 32-row group in four 16-byte LDS reads, then per value
+        // ONE 32-bit multiply-add for the byte offset from the matrix's scalar base (np <= 16384: the last byte of a
+        // matrix lies below 2^31) -- a per-value choice between the two sources costs an LDS round trip and three
+        // branches per value (measured: it did, for a round).
+        const unsigned ld4 = (unsigned)ld * 4u;
+        const char *srcb = reinterpret_cast<const char *>(src);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            int4 m4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m4[q] = *reinterpret_cast<const int4 *>(&s_map[wr * 64 + tm * 32 + 8 * q + 4 * lhalf]);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const unsigned col4 = (unsigned)(col0 + wc * (BN / 2) + tn * 32 + lcol) * 4u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mm[4] = {m4[q].x, m4[q].y, m4[q].z, m4[q].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[tm][tn][4 * q + j] = __builtin_nontemporal_load(
+                            reinterpret_cast<const float *>(srcb + ((unsigned)mm[j] * ld4 + col4)));
+                }
             }
         }
+    }
     MI32_RB_STAMP(1);
     MI32_RB_ISSUE(0, 0)
     for (int t = 0; t < nk; ++t) {
@@ -250,7 +276,9 @@ __device__ __forceinline__ void rank_bw2_tile(
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int grow = row0 + wr * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                __builtin_nontemporal_store(acc[tm][tn][reg], dst + (size_t)grow * ld + col);
+                const unsigned boff = (unsigned)grow * ((unsigned)ld * 4u) + (unsigned)col * 4u;
+                __builtin_nontemporal_store(acc[tm][tn][reg],
+                                            reinterpret_cast<float *>(reinterpret_cast<char *>(dst) + boff));
             }
             // the next block's first sub-panels, compact and transposed: registers 4q .. 4q+3 are 4 consecutive rows
 #pragma unroll
