@@ -1204,6 +1204,10 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
         }
     }
     __syncthreads();
+    // 32-bit byte offsets from the matrix's (scalar) base: one v_mad_u32_u24 per access instead of a 64-bit
+    // multiply-add pair (np <= 16384: the last byte of a matrix lies below 2^31)
+    const unsigned ld4 = (unsigned)ld * 4u;
+    const char *srcb = reinterpret_cast<const char *>(src);
     // (1) the W pivot rows' own multipliers: Mt_t[step][index of the row of step kk in order after t-1]
     constexpr int NLT = (BK * BK + 255) / 256;
     float lval[NLT];
@@ -1219,18 +1223,19 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
     for (int q = 0; q < NBQ; ++q) {
         const int idx = tid + q * 256;
         if (idx < BK * 16)
-            bq[q] = *reinterpret_cast<const float4 *>(src + (size_t)T.s_pmap[idx / 16] * ld + col0 + (idx % 16) * 4);
+            bq[q] = *reinterpret_cast<const float4 *>(
+                srcb + ((unsigned)T.s_pmap[idx / 16] * ld4 + (unsigned)(col0 + (idx % 16) * 4) * 4u));
     }
     // (3) the accumulators start from the (row-mapped) old values
     float16v acc;
     const int lcol = lane & 31;
     const int lhalf = lane >> 5;
     {
-        const int col = col0 + wc * 32 + lcol;
+        const unsigned col4 = (unsigned)(col0 + wc * 32 + lcol) * 4u;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int lr = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-            acc[reg] = src[(size_t)T.s_map[lr] * ld + col];
+            acc[reg] = *reinterpret_cast<const float *>(srcb + ((unsigned)T.s_map[lr] * ld4 + col4));
         }
     }
     {
@@ -1327,7 +1332,7 @@ __device__ __forceinline__ void inblock_update_body(const SubpanelArgs &A, int u
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int grow = row0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                dst[(size_t)grow * ld + col] = acc[reg];
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(dst) + ((unsigned)grow * ld4 + (unsigned)col * 4u)) = acc[reg];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)  // registers 4q .. 4q+3 are 4 consecutive rows: one 16-byte store
