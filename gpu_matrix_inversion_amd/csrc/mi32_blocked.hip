@@ -914,12 +914,26 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     const int *rowsrc_in = A.rowsrc_in + (size_t)b * np;
     int *rowsrc = A.rowsrc_out + (size_t)b * np;
     int *orig = A.orig + (size_t)b * np;
+    // All 2 * RPT loads are requested before the first is used (addresses clamped instead of guarded: behind a
+    // condition hipcc waits for each load before it issues the next -- eight dependent round trips in front of the
+    // first pivot step of a 4-rows-per-lane panel).
+    {
+        int pr[RPT], po[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int row = row_lo + panel_row<NT, RPT>(tid, k);
-        const int p0 = (int)(npl[k] ^ (unsigned)((int)npl[k] >> 31));
-        s_park[k * NT + tid] = (A.first_in_block || row >= np) ? p0 : rowsrc_in[p0];  // composite map so far
-        s_park[(RPT + k) * NT + tid] = row < np ? orig[p0] : 0;
+        for (int k = 0; k < RPT; ++k) {
+            const int row = row_lo + panel_row<NT, RPT>(tid, k);
+            const int p0 = (int)(npl[k] ^ (unsigned)((int)npl[k] >> 31));
+            const int pi = row < np ? p0 : 0;
+            pr[k] = rowsrc_in[pi];
+            po[k] = orig[pi];
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int row = row_lo + panel_row<NT, RPT>(tid, k);
+            const int p0 = (int)(npl[k] ^ (unsigned)((int)npl[k] >> 31));
+            s_park[k * NT + tid] = (A.first_in_block || row >= np) ? p0 : pr[k];  // composite map so far
+            s_park[(RPT + k) * NT + tid] = row < np ? po[k] : 0;
+        }
     }
     // rows above the block keep their place: identity entries in the maps the update kernels read
     if (A.first_in_block && grp == 0) {
