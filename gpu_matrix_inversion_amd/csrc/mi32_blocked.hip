@@ -1050,6 +1050,11 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     float *mt_lane = FUSED ? mt : mt + row_lo;  // wave-uniform; the lane's part is added by the store
     panel_steps<NT, RPT, W, MULTI, FUSED>(a, npl, moff, sh, wave_u, c0, true, singular, pg, mt_lane, mtld,
                                           std::make_integer_sequence<int, W>{});
+    // The thread index, recomputed behind an opaque instruction: everything the epilogue addresses hangs on it, so
+    // hipcc cannot compute those addresses in front of the steps and carry them through (it spilled them).
+    int tid_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid_e));
+    tid_e += wave_u * 64;
     int pos[RPT];  // final position of every register row
 #pragma unroll
     for (int k = 0; k < RPT; ++k) pos[k] = (int)(npl[k] ^ (unsigned)((int)npl[k] >> 31));
@@ -1060,7 +1065,7 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     MI32_PSTAMP(A.tag_base, 48);
     float *aux = A.aux_out + (size_t)b * kAuxFloats;
     if (grp == 0)
-        for (int i = tid; i < W * W; i += NT) {
+        for (int i = tid_e; i < W * W; i += NT) {
             aux[i] = sh.prn_all[i / W][i % W];
             if (has_prev) aux[kMaxW * kMaxW + i] = sh.uprev[i / W][i % W];
         }
@@ -1069,11 +1074,11 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
     int *submap = A.submap_out + (size_t)b * np;
     int *invsub = A.invsub_out + (size_t)b * np;
     // positions retired since this map buffer was last written: identity (any earlier position already is)
-    if (grp == 0 && tid < 4 * kMaxW && row_lo - 4 * kMaxW + tid >= 0)
-        submap[row_lo - 4 * kMaxW + tid] = row_lo - 4 * kMaxW + tid;
+    if (grp == 0 && tid_e < 4 * kMaxW && row_lo - 4 * kMaxW + tid_e >= 0)
+        submap[row_lo - 4 * kMaxW + tid_e] = row_lo - 4 * kMaxW + tid_e;
 #pragma unroll
     for (int g = 0; g < RPT / V; ++g) {
-        const int row = row_lo + panel_row<NT, RPT>(tid, g * V);
+        const int row = row_lo + panel_row<NT, RPT>(tid_e, g * V);
         if (row < np) {
             ivecV p0;  // the labels at entry, again (no registers were kept for them)
 #pragma unroll
@@ -1101,8 +1106,8 @@ __device__ __forceinline__ void panel_body(const SubpanelArgs &A, int b, int grp
                 const int k = g * V + j;
                 submap[pos[k]] = p0[j];  // position pos[k] now holds what lies at index p0[j] of the order after s-1
                 invsub[p0[j]] = pos[k];
-                rowsrc[pos[k]] = s_park[k * NT + tid];
-                orig[pos[k]] = s_park[(RPT + k) * NT + tid];
+                rowsrc[pos[k]] = s_park[k * NT + tid_e];
+                orig[pos[k]] = s_park[(RPT + k) * NT + tid_e];
             }
         }
     }
