@@ -605,7 +605,9 @@ __device__ __forceinline__ void panel_step(float (&a)[RPT][W], unsigned (&npl)[R
         for (int k = 0; k < RPT; ++k) {
             const unsigned lm = (unsigned)((int)npl[k] >> 31);                    // all ones while live
             const unsigned key = __float_as_uint(col[k]) & lm & 0x7fffffffu;
-            const bool better = (((unsigned long long)key << 32) | npl[k]) > (((unsigned long long)mkey << 32) | mnp);
+            // (two 32-bit compares, not one 64-bit compare: the register pairs a v_cmp_gt_u64 needs cost the 128-VGPR
+            // instances copies and spills in the middle of the steps)
+            const bool better = key > mkey || (key == mkey && npl[k] > mnp);
             mkey = better ? key : mkey;
             mnp = better ? npl[k] : mnp;
             kb = better ? k : kb;
