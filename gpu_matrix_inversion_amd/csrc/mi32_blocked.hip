@@ -1667,15 +1667,38 @@ __global__ __launch_bounds__(SNT, 4) void gj_block_strip_kernel(const float *__r
     // this wave's tiles of the pivot rows: from the working copy (through the row map) or from where the call for
     // the earlier groups parked them
     float16v acc[kStripTPW];
+    // (the source is chosen once, not per value: per value hipcc emits a branch pair and an LDS round trip for the map
+    // entry in front of every load; 32-bit byte offsets from the scalar base)
+    if (g_lo == 0) {
+        const unsigned ld4 = (unsigned)ld * 4u;
+        const char *srcb = reinterpret_cast<const char *>(src);
 #pragma unroll
-    for (int ti = 0; ti < kStripTPW; ++ti) {
-        const int t = wave + ti * (NT / 64);
-        if (t < ntiles) {
-            const int rt = t / CTT, col = col0 + (t % CTT) * 32 + lcol;
+        for (int ti = 0; ti < kStripTPW; ++ti) {
+            const int t = wave + ti * (NT / 64);
+            if (t < ntiles) {
+                const int rt = t / CTT;
+                const unsigned col4 = (unsigned)(col0 + (t % CTT) * 32 + lcol) * 4u;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
-                acc[ti][reg] = (g_lo == 0) ? src[(size_t)s_q[r] * ld + col] : xst[(size_t)r * np + col];
+                for (int q = 0; q < 4; ++q) {
+                    const int4 m4 = *reinterpret_cast<const int4 *>(&s_q[rt * 32 + 8 * q + 4 * lhalf]);
+                    const int mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[ti][4 * q + j] = *reinterpret_cast<const float *>(srcb + ((unsigned)mm[j] * ld4 + col4));
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ti = 0; ti < kStripTPW; ++ti) {
+            const int t = wave + ti * (NT / 64);
+            if (t < ntiles) {
+                const int rt = t / CTT, col = col0 + (t % CTT) * 32 + lcol;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lhalf;
+                    acc[ti][reg] = xst[(size_t)r * np + col];
+                }
             }
         }
     }
