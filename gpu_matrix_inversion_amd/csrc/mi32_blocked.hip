@@ -150,6 +150,8 @@ BlockedPlan make_blocked_plan(int n, int w, int bw, int batch)
     }
     return p;
 }
+// (the update tiles address a matrix with 32-bit byte offsets from its base: mi32_rank_bw.h, inblock_update_body)
+static_assert(16384ull * (16384 + 64) * sizeof(float) < (1ull << 32), "a working copy must stay below 4 GiB");
 bool blocked_supported(int n) { return n > 0 && ((n + 127) & ~127) <= 16384; }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
